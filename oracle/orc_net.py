@@ -1,0 +1,368 @@
+"""CPU ORACLE, network level.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module; the product (darknet_amd/, include/) never does.
+
+It restates, on top of the per-op C restatement in orc_ops.c (loaded through
+ctypes), the reference's loader and layer loop for the YOLOv4 family:
+
+  * ReadSections / option lookup ........ src/parser.cpp:59-100,
+                                          src/option_list.cpp:134-243,
+                                          strip(): src/utils.cpp:133-148
+  * ParseNetOptions ..................... src/parser.cpp:921-1055
+  * ParseConv / Yolo / Maxpool / Route /
+    Shortcut / Upsample ................. src/parser.cpp:179-242, 312-415,
+                                          640-659, 828-893, 720-779, 820-826
+  * ParseNetworkCfg layer loop .......... src/parser.cpp:1076-1519
+  * LoadWeightsUpTo / LoadConvolutionalWeights  src/parser.cpp:1778-1844, 1695-1759
+  * FuseConvBatchNorm ................... src/network.cpp:647-682
+  * ForwardNetwork / NetworkPredict ..... src/network.cpp:101-114, 412-430
+  * GetNetworkBoxes ..................... src/network.cpp:432-516
+
+Pinned against the real reference (oracle/_ref/libref_canon.so) by
+tests/test_oracle_vs_ref.py in the build container, and against the committed
+golden fixtures everywhere.
+"""
+import ctypes as C
+import os
+import struct
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# enum values, src/yolo_core.h:69-92 and :112-138
+LOGISTIC, RELU, LINEAR, LEAKY, MISH = 0, 1, 4, 8, 17
+ACT_NAMES = {"logistic": LOGISTIC, "relu": RELU, "linear": LINEAR,
+             "leaky": LEAKY, "mish": MISH}
+CONVOLUTIONAL, MAXPOOL, ROUTE, SHORTCUT, YOLO, UPSAMPLE = 0, 2, 7, 11, 17, 21
+
+_lib = None
+
+
+def build():
+    """Compile orc_ops.c -> liborc.so (gcc -O2 -ffp-contract=off -fopenmp)."""
+    subprocess.check_call(["make", "-s", "-C", HERE, "oracle"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(HERE, "liborc.so")
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(
+                os.path.join(HERE, "orc_ops.c")):
+            build()
+        _lib = C.CDLL(path)
+        _lib.orc_num_threads.restype = C.c_int
+        _lib.orc_yolo_num_detections.restype = C.c_int
+        _lib.orc_yolo_detections.restype = C.c_int
+    return _lib
+
+
+def fptr(a):
+    if a is None:
+        return C.POINTER(C.c_float)()
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def iptr(a):
+    if a is None:
+        return C.POINTER(C.c_int)()
+    assert a.dtype == np.int32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+F = C.c_float
+
+
+# ------------------------------------------------------------------ cfg parse
+def read_sections(path):
+    """ReadSections: every space/tab/CR/LF is stripped from each line, '[' opens
+    a section, '#', ';' and empty lines are skipped, the rest is key=value split
+    at the first '='."""
+    sections = []
+    with open(path) as f:
+        for raw in f:
+            line = "".join(ch for ch in raw if ch not in " \t\r\n")
+            if not line or line[0] in "#;":
+                continue
+            if line[0] == "[":
+                sections.append((line, {}))
+            else:
+                if "=" not in line:
+                    continue
+                k, v = line.split("=", 1)
+                sections[-1][1][k] = v
+    return sections
+
+
+def _int(o, k, d):
+    return int(o[k]) if k in o else d
+
+
+def _float(o, k, d):
+    return float(o[k]) if k in o else d
+
+
+class Layer:
+    pass
+
+
+class Net:
+    pass
+
+
+def parse_cfg(path, batch=1, train=False):
+    """ParseNetworkCfg restricted to the YOLOv4 family's layer kinds.
+    `batch` overrides the reference's forced batch=1 for inference
+    (src/parser.cpp:1114-1115); in train mode pass batch=None to use
+    batch/subdivisions from the cfg (:927-929)."""
+    secs = read_sections(path)
+    assert secs and secs[0][0] in ("[net]", "[network]")
+    o = secs[0][1]
+    net = Net()
+    net.cfg_batch = _int(o, "batch", 1)
+    net.subdiv = _int(o, "subdivisions", 1)
+    net.batch = batch if batch is not None else net.cfg_batch // net.subdiv
+    net.h, net.w, net.c = _int(o, "height", 0), _int(o, "width", 0), _int(o, "channels", 0)
+    net.lr = _float(o, "learning_rate", .001)
+    net.momentum = _float(o, "momentum", .9)
+    net.decay = _float(o, "decay", .0001)
+    net.burn_in = _int(o, "burn_in", 0)
+    net.power = _float(o, "power", 4)
+    net.max_epoch = _int(o, "max_epoch", 0)
+    net.policy = o.get("policy", "constant")
+    net.steps = [float(x) for x in o["steps"].split(",")] if "steps" in o else []
+    net.scales = [float(x) for x in o["scales"].split(",")] if "scales" in o else []
+    net.train = train
+    net.layers = []
+    h, w, c = net.h, net.w, net.c
+    inputs = h * w * c
+    for idx, (name, o) in enumerate(secs[1:]):
+        l = Layer()
+        l.index = idx
+        l.batch = net.batch
+        l.h, l.w, l.c = h, w, c
+        l.inputs = inputs
+        if name == "[convolutional]":
+            l.type = CONVOLUTIONAL
+            l.n = _int(o, "filters", 1)
+            l.groups = max(1, _int(o, "groups", 1))
+            l.size = _int(o, "size", 1)
+            stride = _int(o, "stride", 1)
+            l.stride_x = _int(o, "stride_x", -1)
+            l.stride_y = _int(o, "stride_y", -1)
+            if l.stride_x < 1:
+                l.stride_x = stride
+            if l.stride_y < 1:
+                l.stride_y = stride
+            l.dilation = _int(o, "dilation", 1)
+            if l.size == 1:
+                l.dilation = 1
+            pad = _int(o, "pad", 0)
+            l.pad = _int(o, "padding", 0)
+            if pad:
+                l.pad = l.size // 2
+            l.activation = ACT_NAMES[o.get("activation", "logistic")]
+            l.batch_normalize = _int(o, "batch_normalize", 0)
+            l.out_h = (h + 2 * l.pad - l.size) // l.stride_y + 1
+            l.out_w = (w + 2 * l.pad - l.size) // l.stride_x + 1
+            l.out_c = l.n
+            l.nweights = (c // l.groups) * l.n * l.size * l.size
+            # l->bflops, src/convolutional_layer.cpp:714
+            l.bflops = (2.0 * l.nweights * l.out_h * l.out_w) / 1000000000.
+            l.workspace = l.out_h * l.out_w * l.size * l.size * (c // l.groups)
+        elif name == "[maxpool]":
+            l.type = MAXPOOL
+            stride = _int(o, "stride", 1)
+            l.stride_x = _int(o, "stride_x", stride)
+            l.stride_y = _int(o, "stride_y", stride)
+            l.size = _int(o, "size", stride)
+            l.pad = _int(o, "padding", l.size - 1)
+            l.out_w = (w + l.pad - l.size) // l.stride_x + 1
+            l.out_h = (h + l.pad - l.size) // l.stride_y + 1
+            l.out_c = c
+            # src/maxpool_layer.cpp:95 (float division of an int product)
+            l.bflops = (l.size * l.size * c * l.out_h * l.out_w) / 1000000000.
+        elif name == "[route]":
+            l.type = ROUTE
+            ids = [int(x) for x in o["layers"].split(",")]
+            l.input_layers = [i if i >= 0 else idx + i for i in ids]
+            l.input_sizes = [net.layers[i].outputs for i in l.input_layers]
+            l.groups = _int(o, "groups", 1)
+            l.group_id = _int(o, "group_id", 0)
+            first = net.layers[l.input_layers[0]]
+            l.out_w, l.out_h = first.out_w, first.out_h
+            l.out_c = sum(net.layers[i].out_c for i in l.input_layers) // l.groups
+            l.bflops = 0
+        elif name == "[shortcut]":
+            l.type = SHORTCUT
+            frm = int(o["from"].split(",")[0])
+            l.from_index = frm if frm >= 0 else idx + frm
+            l.activation = ACT_NAMES[o.get("activation", "linear")]
+            l.out_w, l.out_h, l.out_c = w, h, c
+            src = net.layers[l.from_index]
+            assert (src.out_w, src.out_h, src.out_c) == (w, h, c)
+            # src/shortcut_layer.c: bflops = out_w*out_h*out_c*n / 1e9
+            l.bflops = (l.out_w * l.out_h * l.out_c * 1) / 1000000000.
+        elif name == "[upsample]":
+            l.type = UPSAMPLE
+            l.stride = _int(o, "stride", 2)
+            l.scale = _float(o, "scale", 1)
+            l.out_w, l.out_h, l.out_c = w * l.stride, h * l.stride, c
+            l.bflops = 0
+        elif name == "[yolo]":
+            l.type = YOLO
+            l.classes = _int(o, "classes", 20)
+            l.total = _int(o, "num", 1)
+            l.mask = [int(x) for x in o["mask"].split(",")] if "mask" in o \
+                else list(range(l.total))
+            l.n = len(l.mask)
+            l.scale_x_y = _float(o, "scale_x_y", 1)
+            l.biases = np.full(l.total * 2, .5, np.float32)
+            if "anchors" in o:
+                a = [float(x) for x in o["anchors"].split(",")]
+                for i in range(min(len(a), l.total * 2)):
+                    l.biases[i] = a[i]
+            l.nms_kind = {"greedynms": 0, "diounms": 1}.get(o.get("nms_kind", "greedynms"), 0)
+            l.beta_nms = _float(o, "beta_nms", 0.6)
+            l.out_w, l.out_h = w, h
+            l.out_c = l.n * (l.classes + 4 + 1)
+            assert l.out_c == c, "filters= before [yolo] does not match classes/mask"
+            l.bflops = 0
+        else:
+            raise ValueError("oracle: unsupported section %s" % name)
+        l.outputs = l.out_h * l.out_w * l.out_c
+        net.layers.append(l)
+        h, w, c = l.out_h, l.out_w, l.out_c
+        inputs = l.outputs
+    net.n = len(net.layers)
+    net.bflops = float(np.float32(sum(np.float32(l.bflops) for l in net.layers if l.bflops > 0)))
+    net.workspace = max([getattr(l, "workspace", 0) for l in net.layers] + [1])
+    return net
+
+
+# ----------------------------------------------------------------- weights IO
+def load_weights(net, path):
+    """LoadWeightsUpTo: header int32 major, minor, revision + uint64 seen, then
+    per conv: biases[n], (scales, rolling_mean, rolling_variance)[n] if BN,
+    weights[nweights].  Returns the number of bytes consumed."""
+    with open(path, "rb") as f:
+        buf = f.read()
+    major, minor, rev = struct.unpack_from("<iii", buf, 0)
+    (net.seen,) = struct.unpack_from("<Q", buf, 12)
+    off = 20
+
+    def take(n):
+        nonlocal off
+        a = np.frombuffer(buf, np.float32, n, off).copy()
+        off += 4 * n
+        return a
+
+    for l in net.layers:
+        if l.type != CONVOLUTIONAL:
+            continue
+        l.biases = take(l.n)
+        if l.batch_normalize:
+            l.scales = take(l.n)
+            l.rolling_mean = take(l.n)
+            l.rolling_variance = take(l.n)
+        l.weights = take(l.nweights)
+    return off
+
+
+def weights_file_size(net):
+    n = 20
+    for l in net.layers:
+        if l.type == CONVOLUTIONAL:
+            n += 4 * (l.n + l.nweights + (3 * l.n if l.batch_normalize else 0))
+    return n
+
+
+def fuse_conv_batchnorm(net):
+    """FuseConvBatchNorm for every BN conv; sets batch_normalize = 0."""
+    L = lib()
+    for l in net.layers:
+        if l.type == CONVOLUTIONAL and l.batch_normalize:
+            L.orc_fuse_conv_bn(fptr(l.weights), fptr(l.biases), fptr(l.scales),
+                               fptr(l.rolling_mean), fptr(l.rolling_variance),
+                               l.n, l.size * l.size * l.c // l.groups)
+            l.batch_normalize = 0
+
+
+def load_network(cfg, weights, batch=1):
+    """LoadNetwork(train=false): parse, load, fuse (src/parser.cpp:1852-1876)."""
+    net = parse_cfg(cfg, batch=batch, train=False)
+    if weights:
+        load_weights(net, weights)
+        fuse_conv_batchnorm(net)
+    return net
+
+
+# -------------------------------------------------------------------- forward
+def forward(net, x, keep=None, upto=None):
+    """ForwardNetwork in inference mode (BN folded).  x: float32 [batch, c*h*w].
+    Every layer's output is kept in l.output (as the reference does)."""
+    L = lib()
+    x = np.ascontiguousarray(x, np.float32).reshape(net.batch, -1)
+    ws = np.zeros(net.workspace, np.float32)
+    inp = x
+    for l in net.layers:
+        if upto is not None and l.index > upto:
+            break
+        B = l.batch
+        out = np.zeros((B, l.outputs), np.float32)
+        if l.type == CONVOLUTIONAL:
+            assert not l.batch_normalize, "inference oracle expects fused BN"
+            L.orc_conv_forward_fused(fptr(inp), fptr(l.weights), fptr(l.biases),
+                                     fptr(out), fptr(ws), None, B, l.c, l.h, l.w,
+                                     l.n, l.groups, l.size, l.stride_x, l.stride_y,
+                                     l.dilation, l.pad, l.activation)
+        elif l.type == MAXPOOL:
+            L.orc_maxpool_forward(fptr(inp), fptr(out), None, B, l.c, l.h, l.w,
+                                  l.size, l.stride_x, l.stride_y, l.pad)
+        elif l.type == ROUTE:
+            off = 0
+            for src, size in zip(l.input_layers, l.input_sizes):
+                L.orc_route_copy(fptr(net.layers[src].output), size, l.groups,
+                                 l.group_id, B, fptr(out), l.outputs, off)
+                off += size // l.groups
+        elif l.type == SHORTCUT:
+            L.orc_shortcut_forward(fptr(inp), fptr(net.layers[l.from_index].output),
+                                   fptr(out), B * l.outputs)
+            L.orc_activate_array(fptr(out), B * l.outputs, l.activation)
+        elif l.type == UPSAMPLE:
+            L.orc_upsample_forward(fptr(inp), l.w, l.h, l.c, B, l.stride,
+                                   F(l.scale), fptr(out))
+        elif l.type == YOLO:
+            L.orc_yolo_forward(fptr(inp), fptr(out), B, l.w, l.h, l.n, l.classes,
+                               F(l.scale_x_y))
+        l.output = out
+        inp = out
+    return inp
+
+
+def get_boxes(net, thresh, b=0):
+    """GetNetworkBoxes for batch item b: (dets [num, 5+classes], ids [num, 4] =
+    (layer index, anchor, row, col))."""
+    L = lib()
+    dets, ids = [], []
+    for l in net.layers:
+        if l.type != YOLO:
+            continue
+        num = L.orc_yolo_num_detections(fptr(l.output), b, l.w, l.h, l.n,
+                                        l.classes, F(thresh))
+        d = np.zeros((num, 5 + l.classes), np.float32)
+        i3 = np.zeros((num, 3), np.int32)
+        mask = np.array(l.mask, np.int32)
+        got = L.orc_yolo_detections(fptr(l.output), b, l.w, l.h, l.n, l.classes,
+                                    fptr(l.biases), iptr(mask), net.w, net.h,
+                                    F(thresh), fptr(d), iptr(i3))
+        assert got == num
+        dets.append(d)
+        ids.append(np.concatenate([np.full((num, 1), l.index, np.int32), i3], 1))
+    if not dets:
+        return np.zeros((0, 5), np.float32), np.zeros((0, 4), np.int32)
+    return np.concatenate(dets), np.concatenate(ids)
