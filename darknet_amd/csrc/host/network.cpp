@@ -1,0 +1,592 @@
+// network.cpp -- graph engine of the HIP path: layer loop, predict entry points,
+// BN folding, detection collection, plus the MI355X-native planning pass
+// (conv+shortcut epilogue fusion, per-layer tile autotune, hipGraph replay).
+//
+// Reference twins (Ravicmoon/darknet src/): ForwardNetworkGpu network_kernels.cu
+// :45-114, NetworkPredictGpu :502-522, GetNetworkOutputGpu :486-500,
+// NetworkPredict network.cpp:412-430, NumDetections/MakeNetworkBoxes/
+// FillNetworkBoxes/GetNetworkBoxes/FreeDetections :432-516, FuseConvBatchNorm
+// :647-682, GetCurrLr :32-84, FreeNetwork :600-645.
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+
+#include "dk_host.h"
+#include "dk_internal.h"
+
+int g_dk_fusion = 1;
+int g_dk_graph = 1;
+int g_dk_autotune = 1;
+int g_dk_pull_heads = 1;
+
+int DkYoloNumDetectionsBatch(layer const* l, int b, float thresh);
+int DkGetYoloDetectionsBatch(
+    layer const* l, int b, int net_w, int net_h, float thresh, Detection* dets, int* ids);
+void DkConvPrepare(layer* l);
+
+void DkSetFusion(int on) { g_dk_fusion = on; }
+void DkSetGraph(int on) { g_dk_graph = on; }
+void DkSetAutotune(int on) { g_dk_autotune = on; }
+extern "C" LIB_API void DkSetPullHeads(int on) { g_dk_pull_heads = on; }
+
+// ---------------------------------------------------------------------------
+int GetNetworkInputSize(Network* net) { return net->layers[0].inputs; }
+
+int GetNetworkOutputSize(Network* net)
+{
+  int i;
+  for (i = net->n - 1; i > 0; --i)
+    if (net->layers[i].type != COST)
+      break;
+  return net->layers[i].outputs;
+}
+
+float GetCurrLr(Network* net)
+{
+  // network.cpp:32-84 (pow on float arguments is the float overload there)
+  const int64_t iter = net->curr_iter;
+  if (iter < net->burn_in)
+    return net->lr * powf((float)iter / net->burn_in, net->power);
+  switch (net->policy)
+  {
+    case CONSTANT: return net->lr;
+    case STEP: return net->lr * (float)pow((double)net->scale, (double)(iter / net->step));
+    case STEPS:
+    {
+      float lr = net->lr;
+      for (int i = 0; i < net->num_steps; ++i)
+      {
+        if (net->max_iter * net->steps[i] > iter)
+          return lr;
+        lr *= net->scales[i];
+      }
+      return lr;
+    }
+    case EXP: return net->lr * (float)pow((double)net->gamma, (double)iter);
+    case POLY: return net->lr * powf(1 - (float)iter / net->max_iter, net->power);
+    case SIG: return net->lr * (1. / (1. + exp(net->gamma * (iter - net->step))));
+    default: break;
+  }
+  fprintf(stderr, "GetCurrLr: policy %d is outside the supported hot path\n", (int)net->policy);
+  return net->lr;
+}
+
+// FuseConvBatchNorm, network.cpp:647-682 (host arithmetic, then re-push)
+void FuseConvBatchNorm(Network* net)
+{
+  for (int j = 0; j < net->n; ++j)
+  {
+    layer* l = &net->layers[j];
+    if (l->type != CONVOLUTIONAL || !l->batch_normalize)
+      continue;
+    const int filter_size = l->size * l->size * l->c / l->groups;
+    for (int f = 0; f < l->n; ++f)
+    {
+      const float std = sqrtf(l->rolling_variance[f] + 0.00001f);
+      l->biases[f] -= l->scales[f] * l->rolling_mean[f] / std;
+      for (int i = 0; i < filter_size; ++i)
+        l->weights[(size_t)f * filter_size + i] *= l->scales[f] / std;
+    }
+    // free_convolutional_batchnorm: the BN tensors are released
+    free(l->scales); l->scales = nullptr;
+    free(l->rolling_mean); l->rolling_mean = nullptr;
+    free(l->rolling_variance); l->rolling_variance = nullptr;
+    if (dk_gpu_enabled())
+    {
+      cuda_free(l->scales_gpu); l->scales_gpu = nullptr;
+      cuda_free(l->rolling_mean_gpu); l->rolling_mean_gpu = nullptr;
+      cuda_free(l->rolling_variance_gpu); l->rolling_variance_gpu = nullptr;
+    }
+    l->batch_normalize = 0;
+    PushConvolutionalLayer(l);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// planning pass for inference loads
+// ---------------------------------------------------------------------------
+static bool output_referenced_elsewhere(Network* net, int idx, int except_layer)
+{
+  for (int i = 0; i < net->n; ++i)
+  {
+    if (i == except_layer)
+      continue;
+    layer* l = &net->layers[i];
+    if (l->type == ROUTE)
+      for (int k = 0; k < l->n; ++k)
+        if (l->input_layers[k] == idx)
+          return true;
+    if (l->type == SHORTCUT && l->index == idx)
+      return true;
+  }
+  return false;
+}
+
+static void run_layers_eager(Network* net, NetworkState state)
+{
+  for (int i = 0; i < net->n; ++i)
+  {
+    state.index = i;
+    layer* l = &net->layers[i];
+    if (l->forward_gpu)
+      l->forward_gpu(l, state);
+    if (l->output_gpu)
+      state.input = l->output_gpu;
+  }
+}
+
+void DkInvalidateGraph(Network* net)
+{
+  if (net->graph_exec)
+  {
+    (void)hipGraphExecDestroy((hipGraphExec_t)net->graph_exec);
+    net->graph_exec = nullptr;
+  }
+}
+
+static void autotune_convs(Network* net)
+{
+  const int ncfg = dk_conv_num_configs();
+  hipStream_t st = get_cuda_stream();
+  hipEvent_t e0, e1;
+  CHECK_HIP(hipEventCreate(&e0));
+  CHECK_HIP(hipEventCreate(&e1));
+  // sane values in every buffer first
+  const size_t in_n = (size_t)GetNetworkInputSize(net) * net->batch;
+  dk_fill(in_n, 0.5f, net->input_state_gpu, st);
+  NetworkState state;
+  memset(&state, 0, sizeof(state));
+  state.net = net;
+  state.input = net->input_state_gpu;
+  state.workspace = net->workspace;
+  run_layers_eager(net, state);
+  CHECK_HIP(hipStreamSynchronize(st));
+
+  std::map<std::vector<int>, int> cache;
+  float* in = net->input_state_gpu;
+  for (int i = 0; i < net->n; ++i)
+  {
+    layer* l = &net->layers[i];
+    if (l->type == CONVOLUTIONAL && !l->batch_normalize)
+    {
+      std::vector<int> key = {l->batch, l->c, l->h, l->w, l->n, l->groups, l->size, l->stride_x,
+          l->stride_y, l->dilation, l->pad, (int)l->activation, l->fuse_residual_from >= 0};
+      auto it = cache.find(key);
+      if (it != cache.end())
+        l->conv_cfg = it->second;
+      else
+      {
+        NetworkState s = state;
+        s.input = in;
+        s.index = i;
+        int best = -1;
+        float best_ms = 1e30f;
+        for (int c = 0; c < ncfg; ++c)
+        {
+          l->conv_cfg = c;
+          l->forward_gpu(l, s);  // warm
+          CHECK_HIP(hipEventRecord(e0, st));
+          l->forward_gpu(l, s);
+          l->forward_gpu(l, s);
+          CHECK_HIP(hipEventRecord(e1, st));
+          CHECK_HIP(hipEventSynchronize(e1));
+          float ms = 0;
+          CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+          if (ms < best_ms)
+          {
+            best_ms = ms;
+            best = c;
+          }
+        }
+        l->conv_cfg = best;
+        cache[key] = best;
+      }
+    }
+    if (l->output_gpu)
+      in = l->output_gpu;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+}
+
+void DkPlanInference(Network* net)
+{
+  // 1. conv + shortcut(linear) epilogue fusion
+  for (int i = 1; i < net->n; ++i)
+  {
+    layer* sc = &net->layers[i];
+    layer* cv = &net->layers[i - 1];
+    sc->fused_into_prev = 0;
+    if (cv->type == CONVOLUTIONAL)
+      cv->fuse_residual_from = -1;
+    if (!g_dk_fusion)
+      continue;
+    if (sc->type != SHORTCUT || sc->activation != LINEAR || cv->type != CONVOLUTIONAL ||
+        cv->batch_normalize)
+      continue;
+    layer* from = &net->layers[sc->index];
+    if (from->out_w != sc->w || from->out_h != sc->h || from->out_c != sc->c)
+      continue;
+    if (sc->index == i - 1 || output_referenced_elsewhere(net, i - 1, i))
+      continue;
+    cv->fuse_residual_from = sc->index;
+    sc->fused_into_prev = 1;
+  }
+  // 2. tap tables (must exist before any stream capture)
+  for (int i = 0; i < net->n; ++i)
+    if (net->layers[i].type == CONVOLUTIONAL)
+      DkConvPrepare(&net->layers[i]);
+  // 3. per-layer tile choice
+  const char* e = getenv("DK_AUTOTUNE");
+  const bool tune = e ? atoi(e) != 0 : g_dk_autotune != 0;
+  if (tune)
+    autotune_convs(net);
+  DkInvalidateGraph(net);
+}
+
+// ---------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------
+void ForwardNetworkGpu(Network* net, NetworkState state)
+{
+  state.workspace = net->workspace;
+  hipStream_t st = get_cuda_stream();
+  for (int i = 0; i < net->n; ++i)
+  {
+    state.index = i;
+    layer* l = &net->layers[i];
+    if (l->delta_gpu && state.train)
+      CHECK_HIP(hipMemsetAsync(l->delta_gpu, 0, (size_t)l->outputs * l->batch * sizeof(float), st));
+    std::chrono::steady_clock::time_point t0;
+    if (net->benchmark_layers)
+    {
+      CHECK_HIP(hipStreamSynchronize(st));
+      t0 = std::chrono::steady_clock::now();
+    }
+    if (l->forward_gpu)
+      l->forward_gpu(l, state);
+    if (net->benchmark_layers)
+    {
+      CHECK_HIP(hipStreamSynchronize(st));
+      const double ms =
+          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      printf("\n fw-layer %d - type: %d - %lf ms \n", i, (int)l->type, ms);
+    }
+    if (net->wait_stream)
+      CHECK_HIP(hipStreamSynchronize(st));
+    if (l->output_gpu)
+      state.input = l->output_gpu;
+  }
+}
+
+static hipEvent_t g_fwd_done[16], g_copy_done[16];
+static int g_ev_init[16];
+static int g_copy_pending[16];
+
+static void ensure_events(int dev)
+{
+  if (!g_ev_init[dev])
+  {
+    CHECK_HIP(hipEventCreateWithFlags(&g_fwd_done[dev], hipEventDisableTiming));
+    CHECK_HIP(hipEventCreateWithFlags(&g_copy_done[dev], hipEventDisableTiming));
+    g_ev_init[dev] = 1;
+  }
+}
+
+extern "C" int dk_profile_is_on();
+
+void NetworkPredictDevice(Network* net, float* input_gpu)
+{
+  if (net->gpu_index < 0)
+    error("NetworkPredictDevice: network was loaded without a HIP device (no CPU fallback)");
+  if (net->gpu_index != cuda_get_device())
+    cuda_set_device(net->gpu_index);
+  const int dev = net->gpu_index;
+  ensure_events(dev);
+  hipStream_t st = get_cuda_stream();
+  NetworkState state;
+  memset(&state, 0, sizeof(state));
+  state.net = net;
+  state.input = input_gpu ? input_gpu : net->input_state_gpu;
+  state.train = 0;
+
+  // the previous call's head copies must finish before the heads are rewritten
+  if (g_copy_pending[dev])
+  {
+    CHECK_HIP(hipStreamWaitEvent(st, g_copy_done[dev], 0));
+    g_copy_pending[dev] = 0;
+  }
+
+  const bool can_graph = g_dk_graph && !net->benchmark_layers && !net->wait_stream &&
+                         !dk_profile_is_on() && state.input == net->input_state_gpu;
+  if (can_graph)
+  {
+    if (!net->graph_exec)
+    {
+      hipGraph_t graph = nullptr;
+      CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+      ForwardNetworkGpu(net, state);
+      CHECK_HIP(hipStreamEndCapture(st, &graph));
+      hipGraphExec_t exec = nullptr;
+      CHECK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      CHECK_HIP(hipGraphDestroy(graph));
+      net->graph_exec = exec;
+    }
+    CHECK_HIP(hipGraphLaunch((hipGraphExec_t)net->graph_exec, st));
+  }
+  else
+    ForwardNetworkGpu(net, state);
+
+  if (g_dk_pull_heads)
+  {
+    // yolo heads -> pinned host memory on the copy stream (the reference pulls
+    // them asynchronously inside ForwardYoloLayerGpu, yolo_layer.cpp:854-858)
+    hipStream_t cs = get_cuda_memcpy_stream();
+    CHECK_HIP(hipEventRecord(g_fwd_done[dev], st));
+    CHECK_HIP(hipStreamWaitEvent(cs, g_fwd_done[dev], 0));
+    for (int i = 0; i < net->n; ++i)
+    {
+      layer* l = &net->layers[i];
+      if (l->type == YOLO)
+        CHECK_HIP(hipMemcpyAsync(l->output, l->output_gpu,
+            (size_t)l->batch * l->outputs * sizeof(float), hipMemcpyDeviceToHost, cs));
+    }
+    CHECK_HIP(hipEventRecord(g_copy_done[dev], cs));
+    g_copy_pending[dev] = 1;
+  }
+}
+
+void NetworkSync(Network* net)
+{
+  if (net->gpu_index < 0)
+    return;
+  if (net->gpu_index != cuda_get_device())
+    cuda_set_device(net->gpu_index);
+  CHECK_HIP(hipStreamSynchronize(get_cuda_stream()));
+  CHECK_HIP(hipStreamSynchronize(get_cuda_memcpy_stream()));
+}
+
+float* GetNetworkOutputGpu(Network* net)
+{
+  int i;
+  for (i = net->n - 1; i > 0; --i)
+    if (net->layers[i].type != COST)
+      break;
+  layer* l = &net->layers[i];
+  NetworkSync(net);
+  if (l->type != YOLO || !g_dk_pull_heads)
+    cuda_pull_array(l->output_gpu, l->output, (size_t)l->outputs * l->batch);
+  return l->output;
+}
+
+float* NetworkPredictGpu(Network* net, float* input)
+{
+  if (net->gpu_index < 0)
+    error("NetworkPredict: no HIP device (this library has no CPU fallback)");
+  if (net->gpu_index != cuda_get_device())
+    cuda_set_device(net->gpu_index);
+  const size_t size = (size_t)GetNetworkInputSize(net) * net->batch;
+  memcpy(net->input_pinned_cpu, input, size * sizeof(float));
+  cuda_push_array(net->input_state_gpu, net->input_pinned_cpu, size);
+  NetworkPredictDevice(net, nullptr);
+  return GetNetworkOutputGpu(net);
+}
+
+float* NetworkPredict(Network* net, float* input) { return NetworkPredictGpu(net, input); }
+
+// ---------------------------------------------------------------------------
+// detections (host C++, as in the reference)
+// ---------------------------------------------------------------------------
+static int num_detections(Network* net, int b, float thresh)
+{
+  int s = 0;
+  for (int i = 0; i < net->n; ++i)
+    if (net->layers[i].type == YOLO)
+      s += DkYoloNumDetectionsBatch(&net->layers[i], b, thresh);
+  return s;
+}
+
+static Detection* make_boxes(Network* net, int b, float thresh, int* num)
+{
+  layer* l = &net->layers[net->n - 1];
+  const int num_boxes = num_detections(net, b, thresh);
+  if (num)
+    *num = num_boxes;
+  Detection* dets = (Detection*)xcalloc(num_boxes, sizeof(Detection));
+  for (int i = 0; i < num_boxes; ++i) dets[i].prob = (float*)xcalloc(l->classes, sizeof(float));
+  return dets;
+}
+
+Detection* MakeNetworkBoxes(Network* net, float thresh, int* num)
+{
+  return make_boxes(net, 0, thresh, num);
+}
+
+Detection* GetNetworkBoxesBatch(Network* net, int b, float thresh, int* num)
+{
+  if (b < 0 || b >= net->batch)
+    error("GetNetworkBoxesBatch: batch index out of range");
+  Detection* dets = make_boxes(net, b, thresh, num);
+  Detection* d = dets;
+  for (int i = 0; i < net->n; ++i)
+  {
+    layer* l = &net->layers[i];
+    if (l->type == YOLO)
+      d += DkGetYoloDetectionsBatch(l, b, net->w, net->h, thresh, d, nullptr);
+  }
+  return dets;
+}
+
+Detection* GetNetworkBoxes(Network* net, float thresh, int* num)
+{
+  return GetNetworkBoxesBatch(net, 0, thresh, num);
+}
+
+void FreeDetections(Detection* dets, int n)
+{
+  for (int i = 0; i < n; ++i)
+  {
+    free(dets[i].prob);
+    free(dets[i].uc);
+    free(dets[i].mask);
+  }
+  free(dets);
+}
+
+int DkGetBoxesBatch(Network* net, int b, float thresh, float* out, int* ids, int max_dets)
+{
+  if (b < 0 || b >= net->batch)
+    return -1;
+  int total = 0;
+  for (int i = 0; i < net->n; ++i)
+  {
+    layer* l = &net->layers[i];
+    if (l->type != YOLO)
+      continue;
+    const int num = DkYoloNumDetectionsBatch(l, b, thresh);
+    if (num == 0)
+      continue;
+    Detection* dets = (Detection*)xcalloc(num, sizeof(Detection));
+    for (int k = 0; k < num; ++k) dets[k].prob = (float*)xcalloc(l->classes, sizeof(float));
+    int* lid = (int*)xcalloc((size_t)num * 4, sizeof(int));
+    const int got = DkGetYoloDetectionsBatch(l, b, net->w, net->h, thresh, dets, lid);
+    const int rec = 5 + l->classes;
+    for (int k = 0; k < got; ++k)
+    {
+      if (total + k >= max_dets)
+        break;
+      float* o = out + (size_t)(total + k) * rec;
+      o[0] = dets[k].bbox.x; o[1] = dets[k].bbox.y; o[2] = dets[k].bbox.w; o[3] = dets[k].bbox.h;
+      o[4] = dets[k].objectness;
+      memcpy(o + 5, dets[k].prob, l->classes * sizeof(float));
+      if (ids)
+      {
+        int* q = ids + (size_t)(total + k) * 4;
+        q[0] = i; q[1] = lid[4 * k + 1]; q[2] = lid[4 * k + 2]; q[3] = lid[4 * k + 3];
+      }
+    }
+    total += got;
+    FreeDetections(dets, num);
+    free(lid);
+  }
+  return total;
+}
+
+// ---------------------------------------------------------------------------
+// lifetime + FFI helpers
+// ---------------------------------------------------------------------------
+void FreeNetwork(Network* net)
+{
+  if (!net || !net->layers)
+    return;
+  if (net->gpu_index >= 0)
+  {
+    cuda_set_device(net->gpu_index);
+    NetworkSync(net);
+  }
+  DkInvalidateGraph(net);
+  float* last_out = net->layers[net->n - 1].output;
+  (void)last_out;
+  for (int i = 0; i < net->n; ++i) free_layer(&net->layers[i], false);
+  free(net->layers);
+  free(net->steps);
+  free(net->scales);
+  free(net->input_gpu);
+  free(net->truth_gpu);
+  if (net->gpu_index >= 0)
+  {
+    cuda_free(net->input_state_gpu);
+    if (net->input_pinned_cpu_flag)
+      cuda_free_host(net->input_pinned_cpu);
+    cuda_free(net->workspace);
+  }
+  memset(net, 0, sizeof(*net));
+}
+
+Network* DkNetworkCreate(void) { return (Network*)xcalloc(1, sizeof(Network)); }
+
+void DkNetworkDestroy(Network* net)
+{
+  if (!net)
+    return;
+  FreeNetwork(net);
+  free(net);
+}
+
+float* DkNetworkInputGpu(Network* net) { return net->input_state_gpu; }
+
+void DkNetworkInfo(Network* net, int* o)
+{
+  o[0] = net->n; o[1] = net->batch; o[2] = net->w; o[3] = net->h; o[4] = net->c;
+  o[5] = net->inputs; o[6] = net->outputs; o[7] = net->gpu_index;
+}
+
+void DkLayerInfo(Network* net, int i, int* o)
+{
+  layer* l = &net->layers[i];
+  o[0] = l->type; o[1] = l->batch; o[2] = l->outputs; o[3] = l->out_c; o[4] = l->out_h;
+  o[5] = l->out_w; o[6] = l->n; o[7] = l->size; o[8] = l->stride; o[9] = l->pad; o[10] = l->c;
+  o[11] = l->h; o[12] = l->w; o[13] = l->activation; o[14] = l->batch_normalize;
+  o[15] = l->nweights; o[16] = l->groups; o[17] = l->inputs; o[18] = l->classes; o[19] = l->total;
+  o[20] = l->index; o[21] = l->dilation; o[22] = l->stride_x; o[23] = l->stride_y;
+}
+
+float DkLayerBflops(Network* net, int i) { return net->layers[i].bflops; }
+
+float* DkLayerOutputGpu(Network* net, int i) { return net->layers[i].output_gpu; }
+
+int DkLayerOutput(Network* net, int i, float* dst, size_t n)
+{
+  layer* l = &net->layers[i];
+  const size_t total = (size_t)l->batch * l->outputs;
+  if (!l->output_gpu || n < total)
+    return 1;
+  NetworkSync(net);
+  cuda_pull_array(l->output_gpu, dst, total);
+  return 0;
+}
+
+float* DkLayerHostPtr(Network* net, int i, int which)
+{
+  layer* l = &net->layers[i];
+  switch (which)
+  {
+    case 1: return l->weights;
+    case 2: return l->biases;
+    case 3: return l->scales;
+    case 4: return l->rolling_mean;
+    case 5: return l->rolling_variance;
+  }
+  return nullptr;
+}
+
+extern "C" LIB_API int DkLayerConvCfg(Network* net, int i) { return net->layers[i].conv_cfg; }
+extern "C" LIB_API int DkLayerFused(Network* net, int i)
+{
+  layer* l = &net->layers[i];
+  return l->type == SHORTCUT ? l->fused_into_prev : (l->fuse_residual_from >= 0);
+}

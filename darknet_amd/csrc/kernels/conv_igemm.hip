@@ -1,0 +1,578 @@
+// conv_igemm.hip -- forward convolution as an implicit GEMM on gfx950 fp32 MFMA.
+//
+// Replaces the reference's no-cuDNN GPU branch of ForwardConvolutionalLayerGpu
+// (src/convolutional_kernels.cu:471-532): fill_ongpu, then per image
+// im2col_gpu_ext (src/im2col_kernels.cu:1830-1884) + cublasSgemm
+// (src/gemm.c:3011-3022), then add_bias_gpu and the activation kernel.  Here it
+// is one launch:
+//
+//   Out[m][n] = act( bias[m] + sum_k W[m][k] * X[k][n] ) (+ residual)
+//   m = filter, n = (image b, oy, ox) -- the batch is folded into N,
+//   k = (c, kh, kw) in im2col order (src/im2col.c:56-104).
+//
+// Design (MI355X / CDNA4):
+//  * v_mfma_f32_32x32x2_f32: exact fp32, bitwise a k-ordered fmaf chain, so each
+//    output element accumulates its K products in ascending k exactly like the
+//    reference's gemm_nn (src/gemm.c:2223-2239), with FMA instead of mul+add.
+//  * A = weights tile [BM][BK] and B = gathered input tile [BK][BN] are staged
+//    in LDS (double buffered); the im2col matrix is never materialised: each
+//    thread owns one output pixel column of the B tile, decomposes it into
+//    (b, oy, ox) once, and per k adds a wave-uniform offset from a per-layer
+//    table (scalar loads) to its base address.  Padding is a per-thread bitmask
+//    over the kernel taps; masked loads use buffer_load's bounds check (offset
+//    forced out of range -> 0) so there is no divergent branch.
+//  * B rows are contiguous in n -> conflict-free ds_write_b32 / ds_read_b32;
+//    A rows are padded to BK+1 floats so the 32 lanes of an MFMA A-fragment
+//    read hit 32 different banks.
+//  * One barrier per K tile; global loads for tile t+1 are issued before the
+//    MFMAs of tile t and written to the other LDS buffer after them.
+//  * 1-D grid with a bijective XCD-aware remap so that the M-tiles sharing one
+//    input tile run on the same XCD (shared L2).
+//  * Epilogue fused: bias, LEAKY / MISH / LOGISTIC / RELU / LINEAR, optional
+//    residual add (shortcut fusion) and optional pre-activation store.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "dark_hip.h"
+#include "dk_kernels.h"
+#include "dk_device_math.h"
+#include "dk_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvArgs
+{
+  const float* x;
+  const float* w;
+  const float* bias;
+  float* y;
+  const float* residual;
+  float* act_in;
+  const int2* ktab;  // [Kpad] {element offset of tap k inside one image-group, tap bit index or -1}
+  unsigned x_bytes;  // buffer sizes for the hardware bounds check
+  unsigned w_bytes;
+  int C, H, W;       // channels per group, input height/width
+  int Ctot;          // total input channels
+  int M, Mtot;       // filters per group / total
+  int K;             // C*size*size
+  int OH, OW, OHW;
+  int N;             // batch*OHW
+  int size, stride_x, stride_y, pad, dil;  // pad = l->pad*dilation
+  int act;
+  int tiles_m, tiles_n, groups;
+};
+
+__device__ __forceinline__ float ld_buf(__amdgpu_buffer_rsrc_t r, unsigned byte_off)
+{
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+}
+
+// Bijective XCD remap (8 XCDs, blocks dealt round-robin): block `bid` of `nwg`
+// gets a logical id such that ids handled by one XCD are contiguous.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg)
+{
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+template <int BM, int BN, int BK, int WM, int WN>
+__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
+    conv_igemm_f32(const ConvArgs p)
+{
+  constexpr int NWN = BN / WN;
+  constexpr int NW = (BM / WM) * NWN;
+  constexpr int T = NW * 64;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int AS = BK + 1;                 // padded A row stride (floats)
+  constexpr int A_FLOATS = BM * AS;
+  constexpr int B_FLOATS = BK * BN;
+  constexpr int STAGE = A_FLOATS + B_FLOATS;
+  constexpr int B_ROWS = T / BN;             // B rows gathered per pass
+  constexpr int PB = BK / B_ROWS;            // passes (elements per thread) for B
+  constexpr int A_ROWS = T / BK;             // A rows loaded per pass
+  constexpr int PA = BM / A_ROWS;
+  static_assert(T % BN == 0 && BN % 64 == 0, "B gather mapping");
+  static_assert(BK % B_ROWS == 0 && BM % A_ROWS == 0 && T % BK == 0, "tile mapping");
+
+  __shared__ float lds[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / NWN, wn = wave % NWN;
+
+  // ---- which tile -------------------------------------------------------
+  const int per_group = p.tiles_m * p.tiles_n;
+  int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int g = id / per_group;
+  id -= g * per_group;
+  const int tile_n = id / p.tiles_m;
+  const int tile_m = id - tile_n * p.tiles_m;
+  const int m0 = tile_m * BM;
+  const int n0 = tile_n * BN;
+
+  const int HW = p.H * p.W;
+  const float* wg = p.w + (size_t)g * p.M * p.K;
+  __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)wg, 0, p.w_bytes, 0x00020000);
+
+  // ---- per-thread B column: decompose n once ------------------------------
+  const int bn_l = tid % BN;
+  const int bk_r = __builtin_amdgcn_readfirstlane(tid / BN);  // wave-uniform (BN % 64 == 0)
+  int xbase;      // element offset of (b, group g, iy0, ix0)
+  unsigned mask;  // bit t set <=> tap t is inside the image for this pixel
+  {
+    const int n = n0 + bn_l;
+    const bool nv = n < p.N;
+    const int nn = nv ? n : 0;
+    const int b = nn / p.OHW;
+    const int pix = nn - b * p.OHW;
+    const int oy = pix / p.OW;
+    const int ox = pix - oy * p.OW;
+    const int iy0 = oy * p.stride_y - p.pad;
+    const int ix0 = ox * p.stride_x - p.pad;
+    xbase = (b * p.Ctot + g * p.C) * HW + iy0 * p.W + ix0;
+    mask = 0;
+    if (nv)
+    {
+      for (int kh = 0; kh < p.size; ++kh)
+        for (int kw = 0; kw < p.size; ++kw)
+        {
+          const bool ok = (unsigned)(iy0 + kh * p.dil) < (unsigned)p.H &&
+                          (unsigned)(ix0 + kw * p.dil) < (unsigned)p.W;
+          mask |= (ok ? 1u : 0u) << (kh * p.size + kw);
+        }
+    }
+  }
+
+  // ---- per-thread A element ------------------------------------------------
+  const int ak_l = tid % BK;
+  const int am_r = tid / BK;
+
+  float ra[PA], rb[PB];
+
+  auto load_tile = [&](int k0) {
+    // B: one pixel column, PB taps (wave-uniform k per load)
+#pragma unroll
+    for (int j = 0; j < PB; ++j)
+    {
+      const int k = k0 + bk_r + j * B_ROWS;
+      const int2 kt = p.ktab[k];  // scalar load: k is wave-uniform
+      const bool ok = (kt.y >= 0) && ((mask >> kt.y) & 1u);
+      const unsigned off = ok ? (unsigned)(xbase + kt.x) * 4u : 0xFFFFFFFCu;
+      rb[j] = ld_buf(xr, off);
+    }
+    // A: weights [M][K] row-major
+    {
+      const int k = k0 + ak_l;
+      const bool kv = k < p.K;
+#pragma unroll
+      for (int j = 0; j < PA; ++j)
+      {
+        const int m = m0 + am_r + j * A_ROWS;
+        const bool ok = kv && (m < p.M);
+        const unsigned off = ok ? (unsigned)(m * p.K + k) * 4u : 0xFFFFFFFCu;
+        ra[j] = ld_buf(wr, off);
+      }
+    }
+  };
+
+  auto store_tile = [&](float* st) {
+    float* As = st;
+    float* Bs = st + A_FLOATS;
+#pragma unroll
+    for (int j = 0; j < PA; ++j) As[(am_r + j * A_ROWS) * AS + ak_l] = ra[j];
+#pragma unroll
+    for (int j = 0; j < PB; ++j) Bs[(bk_r + j * B_ROWS) * BN + bn_l] = rb[j];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nkt = (p.K + BK - 1) / BK;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  load_tile(0);
+  store_tile(lds);
+  __syncthreads();
+
+  for (int kt = 0; kt < nkt; ++kt)
+  {
+    float* cur = lds + (kt & 1) * STAGE;
+    const bool more = (kt + 1) < nkt;
+    if (more)
+      load_tile((kt + 1) * BK);
+
+    const float* As = cur + (wm * WM + l31) * AS + lh;
+    const float* Bs = cur + A_FLOATS + lh * BN + wn * WN + l31;
+#pragma unroll
+    for (int s = 0; s < BK / 2; ++s)
+    {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = As[i * 32 * AS + 2 * s];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Bs[(2 * s) * BN + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+
+    if (more)
+      store_tile(lds + ((kt + 1) & 1) * STAGE);
+    __syncthreads();
+  }
+
+  // ---- epilogue -----------------------------------------------------------
+  // C/D layout of 32x32x2: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+  {
+    const int n = n0 + wn * WN + j * 32 + l31;
+    if (n >= p.N)
+      continue;
+    const int b = n / p.OHW;
+    const int pix = n - b * p.OHW;
+    const size_t obase = ((size_t)b * p.Mtot + (size_t)g * p.M) * p.OHW + pix;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+    {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+      {
+        const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m >= p.M)
+          continue;
+        float v = acc[i][j][r];
+        if (p.bias)
+          v += p.bias[g * p.M + m];
+        const size_t o = obase + (size_t)m * p.OHW;
+        if (p.act_in)
+          p.act_in[o] = v;
+        v = dk_activate(v, p.act);
+        if (p.residual)
+          v += p.residual[o];
+        p.y[o] = v;
+      }
+    }
+  }
+}
+
+// --------------------------------------------------------------------------
+// host side: plans (tap table + tile choice), dispatch, profiling
+// --------------------------------------------------------------------------
+namespace
+{
+struct TileCfg
+{
+  int bm, bn, bk, wm, wn;
+  float eff;  // relative MFMA efficiency used by the heuristic
+  const char* name;
+  void (*kernel)(const ConvArgs);
+  int threads;
+};
+
+#define DK_CFG(BM, BN, BK, WM, WN, EFF)                                               \
+  {                                                                                   \
+    BM, BN, BK, WM, WN, EFF, #BM "x" #BN "x" #BK "_w" #WM "x" #WN,                    \
+        conv_igemm_f32<BM, BN, BK, WM, WN>, (BM / WM) * (BN / WN) * 64                \
+  }
+
+const TileCfg g_cfgs[] = {
+    DK_CFG(128, 128, 16, 64, 64, 1.00f),
+    DK_CFG(64, 128, 16, 32, 64, 0.92f),
+    DK_CFG(128, 64, 16, 64, 32, 0.92f),
+    DK_CFG(64, 64, 16, 32, 32, 0.80f),
+    DK_CFG(32, 128, 16, 32, 32, 0.72f),
+    DK_CFG(256, 128, 16, 64, 64, 1.04f),
+};
+const int g_ncfg = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
+
+int g_forced = -1;
+
+struct Plan
+{
+  int2* ktab = nullptr;
+  int kpad = 0;
+};
+
+struct DescKey
+{
+  int v[12];
+  bool operator<(const DescKey& o) const { return memcmp(v, o.v, sizeof(v)) < 0; }
+};
+
+std::mutex g_mu;
+std::map<std::pair<int, DescKey>, Plan> g_plans;  // (device, desc) -> plan
+
+struct ProfRec
+{
+  hipEvent_t e0, e1;
+  int cfg;
+  double gflop;
+};
+int g_prof_on = 0;
+std::vector<ProfRec> g_prof;
+
+int out_dim(int in, int pad, int size, int stride) { return (in + 2 * pad - size) / stride + 1; }
+
+int pick_cfg(int M, long long N, int groups)
+{
+  if (g_forced >= 0 && g_forced < g_ncfg)
+    return g_forced;
+  static int env = -2;
+  if (env == -2)
+  {
+    const char* e = getenv("DK_CONV_CFG");
+    env = e ? atoi(e) : -1;
+  }
+  if (env >= 0 && env < g_ncfg)
+    return env;
+  const int CUS = 256;
+  int best = 0;
+  double best_cost = 1e300;
+  for (int i = 0; i < g_ncfg; ++i)
+  {
+    const TileCfg& c = g_cfgs[i];
+    const long long tiles = (long long)((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn) * groups;
+    const long long rounds = (tiles + CUS - 1) / CUS;
+    // below one full round only the busiest CU matters; beyond, work is conserved
+    const double cost = (double)rounds * c.bm * c.bn / c.eff;
+    if (cost < best_cost * 0.999)
+    {
+      best_cost = cost;
+      best = i;
+    }
+  }
+  return best;
+}
+
+Plan& get_plan(const DkConvDesc* d, int K, int C)
+{
+  DescKey key;
+  memset(&key, 0, sizeof(key));
+  key.v[0] = d->c; key.v[1] = d->h; key.v[2] = d->w; key.v[3] = d->groups;
+  key.v[4] = d->size; key.v[5] = d->dilation;
+  int dev = cuda_get_device();
+  std::lock_guard<std::mutex> lk(g_mu);
+  Plan& pl = g_plans[std::make_pair(dev, key)];
+  if (!pl.ktab)
+  {
+    const int kpad = ((K + 63) / 64) * 64 + 64;
+    std::vector<int2> h(kpad);
+    const int ss = d->size * d->size;
+    for (int k = 0; k < kpad; ++k)
+    {
+      if (k < K)
+      {
+        const int c = k / ss, t = k % ss, kh = t / d->size, kw = t % d->size;
+        h[k].x = c * d->h * d->w + kh * d->dilation * d->w + kw * d->dilation;
+        h[k].y = t;
+      }
+      else
+      {
+        h[k].x = 0;
+        h[k].y = -1;
+      }
+    }
+    CHECK_HIP(hipMalloc((void**)&pl.ktab, kpad * sizeof(int2)));
+    CHECK_HIP(hipMemcpy(pl.ktab, h.data(), kpad * sizeof(int2), hipMemcpyHostToDevice));
+    pl.kpad = kpad;
+    (void)C;
+  }
+  return pl;
+}
+}  // namespace
+
+extern "C" int dk_conv_force_config(int cfg)
+{
+  g_forced = cfg;
+  return g_ncfg;
+}
+
+extern "C" const char* dk_conv_config_name(int cfg)
+{
+  return (cfg >= 0 && cfg < g_ncfg) ? g_cfgs[cfg].name : nullptr;
+}
+
+extern "C" int dk_conv_pick_config(const DkConvDesc* d)
+{
+  const int pad = d->pad * d->dilation;
+  const int eff = d->dilation * (d->size - 1) + 1;
+  const int oh = out_dim(d->h, pad, eff, d->stride_y), ow = out_dim(d->w, pad, eff, d->stride_x);
+  return pick_cfg(d->n / d->groups, (long long)d->batch * oh * ow, d->groups);
+}
+
+extern "C" __attribute__((visibility("default"))) int dk_profile_is_on() { return g_prof_on; }
+
+extern "C" void dk_profile_enable(int on)
+{
+  g_prof_on = on;
+  if (on)
+  {
+    for (auto& r : g_prof)
+    {
+      (void)hipEventDestroy(r.e0);
+      (void)hipEventDestroy(r.e1);
+    }
+    g_prof.clear();
+  }
+}
+
+extern "C" int dk_profile_read(double* out, int max_cfgs)
+{
+  CHECK_HIP(hipDeviceSynchronize());
+  for (int i = 0; i < max_cfgs * 3; ++i) out[i] = 0;
+  for (auto& r : g_prof)
+  {
+    float ms = 0;
+    CHECK_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
+    if (r.cfg < max_cfgs)
+    {
+      out[r.cfg * 3 + 0] += 1;
+      out[r.cfg * 3 + 1] += r.gflop;
+      out[r.cfg * 3 + 2] += ms;
+    }
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  g_prof.clear();
+  return g_ncfg;
+}
+
+int dk_conv_num_configs() { return g_ncfg; }
+
+void dk_conv_prepare(const DkConvDesc* d)
+{
+  const int C = d->c / d->groups;
+  (void)get_plan(d, C * d->size * d->size, C);
+}
+
+extern "C" int dk_conv_forward(const DkConvDesc* d, const float* x, const float* weights,
+    const float* biases, float* y, const float* residual, float* activation_input, void* stream)
+{
+  return dk_conv_forward_cfg(d, x, weights, biases, y, residual, activation_input, stream, -1);
+}
+
+int dk_conv_forward_cfg(const DkConvDesc* d, const float* x, const float* weights,
+    const float* biases, float* y, const float* residual, float* activation_input, void* stream,
+    int cfg_override)
+{
+  if (!d || !x || !weights || !y || d->groups < 1 || d->c % d->groups || d->n % d->groups ||
+      d->size < 1 || d->stride_x < 1 || d->stride_y < 1 || d->dilation < 1)
+  {
+    fprintf(stderr, "dk_conv_forward: invalid descriptor\n");
+    return 1;
+  }
+  if (d->size * d->size > 32)
+  {
+    fprintf(stderr, "dk_conv_forward: kernel size %d unsupported (size*size must be <= 32)\n", d->size);
+    return 1;
+  }
+  const int pad = d->pad * d->dilation;
+  const int keff = d->dilation * (d->size - 1) + 1;
+  const int OH = out_dim(d->h, pad, keff, d->stride_y);
+  const int OW = out_dim(d->w, pad, keff, d->stride_x);
+  if (OH < 1 || OW < 1)
+  {
+    fprintf(stderr, "dk_conv_forward: empty output\n");
+    return 1;
+  }
+  // The reference sizes l->output with ConvOutHeight/Width (no dilation term,
+  // src/convolutional_layer.cpp:87-95) but unfolds with the dilated formula
+  // (src/im2col.c:61-64); the two agree for every cfg darknet generates
+  // (padding = size/2, or dilation 1).  Refuse the inconsistent combinations.
+  if (OH != out_dim(d->h, d->pad, d->size, d->stride_y) ||
+      OW != out_dim(d->w, d->pad, d->size, d->stride_x))
+  {
+    fprintf(stderr, "dk_conv_forward: pad/dilation combination is inconsistent in the reference\n");
+    return 1;
+  }
+  const int C = d->c / d->groups, M = d->n / d->groups, K = C * d->size * d->size;
+  const size_t in_img = (size_t)d->c * d->h * d->w;
+  const size_t out_img = (size_t)d->n * OH * OW;
+  // the gather uses 32-bit byte offsets checked by the buffer descriptor:
+  // process the batch in chunks whose input stays below 4 GiB
+  const size_t max_elems = (size_t)1 << 30;
+  int chunk = d->batch;
+  if (in_img * (size_t)chunk >= max_elems || out_img * (size_t)chunk >= ((size_t)1 << 31))
+  {
+    chunk = (int)((max_elems - 1) / in_img);
+    const int c2 = (int)((((size_t)1 << 31) - 1) / out_img);
+    if (c2 < chunk)
+      chunk = c2;
+    if (chunk < 1)
+    {
+      fprintf(stderr, "dk_conv_forward: one image exceeds the 4 GiB addressing window\n");
+      return 1;
+    }
+  }
+  Plan& pl = get_plan(d, K, C);
+  hipStream_t st = stream ? (hipStream_t)stream : get_cuda_stream();
+
+  for (int b0 = 0; b0 < d->batch; b0 += chunk)
+  {
+    const int nb = (d->batch - b0 < chunk) ? d->batch - b0 : chunk;
+    ConvArgs a;
+    a.x = x + (size_t)b0 * in_img;
+    a.w = weights;
+    a.bias = biases;
+    a.y = y + (size_t)b0 * out_img;
+    a.residual = residual ? residual + (size_t)b0 * out_img : nullptr;
+    a.act_in = activation_input ? activation_input + (size_t)b0 * out_img : nullptr;
+    a.ktab = pl.ktab;
+    a.x_bytes = (unsigned)(in_img * nb * sizeof(float));
+    a.w_bytes = (unsigned)((size_t)M * K * sizeof(float));
+    a.C = C; a.H = d->h; a.W = d->w; a.Ctot = d->c;
+    a.M = M; a.Mtot = d->n; a.K = K;
+    a.OH = OH; a.OW = OW; a.OHW = OH * OW;
+    a.N = nb * OH * OW;
+    a.size = d->size; a.stride_x = d->stride_x; a.stride_y = d->stride_y;
+    a.pad = pad; a.dil = d->dilation;
+    a.act = d->activation;
+    const int ci = (cfg_override >= 0 && cfg_override < g_ncfg) ? cfg_override : pick_cfg(M, a.N, d->groups);
+    const TileCfg& c = g_cfgs[ci];
+    a.tiles_m = (M + c.bm - 1) / c.bm;
+    a.tiles_n = (a.N + c.bn - 1) / c.bn;
+    a.groups = d->groups;
+    const long long nblk = (long long)a.tiles_m * a.tiles_n * d->groups;
+    if (nblk > 0x7fffffffLL)
+    {
+      fprintf(stderr, "dk_conv_forward: grid too large\n");
+      return 1;
+    }
+    ProfRec pr;
+    if (g_prof_on)
+    {
+      CHECK_HIP(hipEventCreate(&pr.e0));
+      CHECK_HIP(hipEventCreate(&pr.e1));
+      CHECK_HIP(hipEventRecord(pr.e0, st));
+    }
+    hipLaunchKernelGGL(c.kernel, dim3((unsigned)nblk), dim3(c.threads), 0, st, a);
+    CHECK_HIP(hipPeekAtLastError());
+    if (g_prof_on)
+    {
+      CHECK_HIP(hipEventRecord(pr.e1, st));
+      pr.cfg = ci;
+      pr.gflop = 2.0 * (double)M * K * d->groups * (double)a.N / 1e9;
+      g_prof.push_back(pr);
+    }
+  }
+  return 0;
+}

@@ -1,0 +1,51 @@
+// dk_device_math.h -- device-side scalar maths shared by the kernels.
+// Each function restates the reference's *CPU* scalar definition (the parity
+// target), with the same float/double choices the reference's C++ build makes.
+#pragma once
+#include <hip/hip_runtime.h>
+
+// ACTIVATION ids, src/yolo_core.h:69-92
+enum
+{
+  DK_LOGISTIC = 0,
+  DK_RELU = 1,
+  DK_LINEAR = 4,
+  DK_LEAKY = 8,
+  DK_MISH = 17
+};
+
+// logistic_activate, src/activations.h:80-83
+__device__ __forceinline__ float dk_logistic(float x) { return 1.f / (1.f + expf(-x)); }
+
+// tanh_activate, src/activations.h:106-109
+__device__ __forceinline__ float dk_tanh(float x) { return (2.f / (1.f + expf(-2.f * x)) - 1.f); }
+
+// softplus_activate, src/activations.h:114-121
+__device__ __forceinline__ float dk_softplus(float x, float threshold)
+{
+  if (x > threshold)
+    return x;
+  else if (x < -threshold)
+    return expf(x);
+  return logf(expf(x) + 1.f);
+}
+
+// mish, src/activations.c:185-197 (MISH_THRESHOLD = 20)
+__device__ __forceinline__ float dk_mish(float x) { return x * dk_tanh(dk_softplus(x, 20.f)); }
+
+// leaky as the reference's scalar CPU path computes it: `.1 * x` with a DOUBLE
+// literal (src/gemm.c:2642), narrowed on store.
+__device__ __forceinline__ float dk_leaky(float x) { return (x > 0.f) ? x : (float)(.1 * (double)x); }
+
+__device__ __forceinline__ float dk_activate(float x, int a)
+{
+  switch (a)
+  {
+    case DK_LINEAR: return x;
+    case DK_LEAKY: return dk_leaky(x);
+    case DK_MISH: return dk_mish(x);
+    case DK_LOGISTIC: return dk_logistic(x);
+    case DK_RELU: return x * (x > 0.f);
+    default: return x;
+  }
+}

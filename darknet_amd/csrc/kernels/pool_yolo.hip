@@ -1,0 +1,128 @@
+// pool_yolo.hip -- maxpool forward and the fused YOLO decode.
+#include <float.h>
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+
+#include "dark_hip.h"
+#include "dk_kernels.h"
+#include "dk_device_math.h"
+
+namespace
+{
+inline hipStream_t S(void* s) { return s ? (hipStream_t)s : get_cuda_stream(); }
+inline int grid_for(size_t work, int threads = 256)
+{
+  size_t b = (work + threads - 1) / threads;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// Definition of ForwardMaxpoolLayer's generic loop (src/maxpool_layer.cpp:255-297)
+// == forward_maxpool_layer_kernel (src/maxpool_layer_kernels.cu:58-101) with the
+// CPU's -FLT_MAX padding value: one thread per output, window scanned row-major,
+// strict '>' (first maximum wins), index = flat input index.
+__global__ void maxpool_kernel(const float* __restrict__ x, float* __restrict__ y,
+    int* __restrict__ indexes, size_t total, int c, int h, int w, int out_h, int out_w, int size,
+    int stride_x, int stride_y, int pad)
+{
+  const int w_off = -pad / 2, h_off = -pad / 2;
+  for (size_t id = blockIdx.x * (size_t)blockDim.x + threadIdx.x; id < total;
+       id += (size_t)gridDim.x * blockDim.x)
+  {
+    const int j = (int)(id % out_w);
+    size_t t = id / out_w;
+    const int i = (int)(t % out_h);
+    const size_t plane = t / out_h;  // b*c + k
+    const float* src = x + plane * h * w;
+    float max = -FLT_MAX;
+    int max_i = -1;
+    const int h0 = h_off + i * stride_y, w0 = w_off + j * stride_x;
+    for (int n = 0; n < size; ++n)
+    {
+      const int cur_h = h0 + n;
+      if ((unsigned)cur_h >= (unsigned)h)
+        continue;
+      for (int m = 0; m < size; ++m)
+      {
+        const int cur_w = w0 + m;
+        if ((unsigned)cur_w >= (unsigned)w)
+          continue;
+        const float val = src[cur_h * w + cur_w];
+        if (val > max)
+        {
+          max = val;
+          max_i = (int)(plane * h * w) + cur_h * w + cur_w;
+        }
+      }
+    }
+    y[id] = max;
+    if (indexes)
+      indexes[id] = max_i;
+  }
+}
+
+// ForwardYoloLayerGpu decode (src/yolo_layer.cpp:836-853) in one launch.
+// entry e of anchor a at location loc lives at b*outputs + a*(5+cls)*wh + e*wh + loc.
+__global__ void yolo_decode_kernel(const float* __restrict__ in, float* __restrict__ out,
+    size_t total, int wh, int entries, float scale_x_y, float beta)
+{
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x)
+  {
+    const int e = (int)((i / wh) % entries);
+    float v = in[i];
+    if (e < 2)
+    {
+      v = dk_logistic(v);
+      v = v * scale_x_y + beta;  // scal_add_cpu, src/blas.c:252-256
+    }
+    else if (e >= 4)
+      v = dk_logistic(v);
+    out[i] = v;
+  }
+}
+}  // namespace
+
+extern "C" int dk_maxpool_forward(const float* x, float* y, int* indexes, int batch, int c, int h,
+    int w, int size, int stride_x, int stride_y, int pad, void* stream)
+{
+  if (!x || !y || size < 1 || stride_x < 1 || stride_y < 1)
+  {
+    fprintf(stderr, "dk_maxpool_forward: invalid arguments\n");
+    return 1;
+  }
+  const int out_w = (w + pad - size) / stride_x + 1;
+  const int out_h = (h + pad - size) / stride_y + 1;
+  const size_t total = (size_t)batch * c * out_h * out_w;
+  if (total == 0)
+    return 0;
+  if ((size_t)batch * c * h * w >= ((size_t)1 << 31))
+  {
+    fprintf(stderr, "dk_maxpool_forward: input too large for int indexes\n");
+    return 1;
+  }
+  hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total)), dim3(256), 0, S(stream), x, y, indexes,
+      total, c, h, w, out_h, out_w, size, stride_x, stride_y, pad);
+  CHECK_HIP(hipPeekAtLastError());
+  return 0;
+}
+
+extern "C" int dk_yolo_forward(const float* in, float* out, int batch, int lw, int lh,
+    int n_anchors, int classes, float scale_x_y, void* stream)
+{
+  if (!in || !out)
+  {
+    fprintf(stderr, "dk_yolo_forward: null pointer\n");
+    return 1;
+  }
+  const int entries = classes + 4 + 1;
+  const size_t total = (size_t)batch * n_anchors * entries * lw * lh;
+  if (total == 0)
+    return 0;
+  const float beta = (float)(-0.5 * (scale_x_y - 1));  // yolo_layer.cpp:400
+  hipLaunchKernelGGL(yolo_decode_kernel, dim3(grid_for(total)), dim3(256), 0, S(stream), in, out,
+      total, lw * lh, entries, scale_x_y, beta);
+  CHECK_HIP(hipPeekAtLastError());
+  return 0;
+}

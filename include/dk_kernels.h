@@ -1,0 +1,126 @@
+/*
+ * dk_kernels.h -- flat C-ABI over the hand-written gfx950 (CDNA4) kernels of the
+ * Darknet convolutional path.  Plain device pointers and sizes only; every
+ * call enqueues on `stream` (a hipStream_t passed as void*; NULL = the
+ * per-device compute stream of dark_hip.h) and does not synchronise.
+ *
+ * Each entry point names the reference GPU function it replaces
+ * (Ravicmoon/darknet, file:line under src/) -- the layer-level drop-ins
+ * (ForwardConvolutionalLayerGpu & co., include/yolo_core_hip.h) are thin
+ * wrappers over these.  Activation ids are the reference's ACTIVATION enum
+ * values (src/yolo_core.h:69-92): LOGISTIC 0, RELU 1, LINEAR 4, LEAKY 8,
+ * MISH 17.  All tensors are fp32 NCHW, batch-major.
+ *
+ * Return value: 0 on success, non-zero (after printing to stderr) on invalid
+ * arguments.  Device errors go through check_error() and exit(), like the
+ * reference (src/dark_cuda.c:85-106).
+ */
+#ifndef DK_KERNELS_H
+#define DK_KERNELS_H
+
+#include <stddef.h>
+
+#ifndef DK_API
+#define DK_API __attribute__((visibility("default")))
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct DkConvDesc
+{
+  int batch;            /* images */
+  int c, h, w;          /* input: total channels, height, width */
+  int n;                /* filters (total output channels) */
+  int groups;
+  int size;             /* square kernel */
+  int stride_x, stride_y;
+  int dilation;
+  int pad;              /* l->pad; effective padding = pad * dilation */
+  int activation;       /* ACTIVATION id applied in the epilogue */
+} DkConvDesc;
+
+/*
+ * Implicit-GEMM forward convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ * Replaces, in one launch, the reference's fill_ongpu + per-image
+ * { im2col_gpu_ext ; gemm_ongpu(cublasSgemm) } loop + add_bias_gpu +
+ * activate_array_ongpu (src/convolutional_kernels.cu:471-532).
+ *   y[b][f][oy][ox] = act( bias[f] + sum_k W[f][k] * im2col(x_b)[k][oy*ow+ox] )
+ *                     (+ residual[b][f][oy][ox] if residual != NULL)
+ * biases may be NULL (treated as 0; used by the training path where BN
+ * follows).  activation_input (may be NULL) receives the pre-activation
+ * value, as activate_array_mish_ongpu stores it (src/activation_kernels.cu:290).
+ * No im2col buffer is materialised and no workspace is needed.
+ */
+DK_API int dk_conv_forward(const DkConvDesc* d, const float* x, const float* weights,
+    const float* biases, float* y, const float* residual,
+    float* activation_input, void* stream);
+
+/* Tile-configuration control for tuning: cfg >= 0 forces one of the compiled
+ * tile shapes for every subsequent dk_conv_forward (-1 = heuristic).  Returns
+ * the number of compiled configurations. */
+DK_API int dk_conv_force_config(int cfg);
+/* Which configuration the heuristic (or the forced value) picks for d. */
+DK_API int dk_conv_pick_config(const DkConvDesc* d);
+/* Human-readable name of configuration cfg, or NULL. */
+DK_API const char* dk_conv_config_name(int cfg);
+
+/* forward_maxpool_layer_kernel, src/maxpool_layer_kernels.cu:58-101: window
+ * origin (i*stride - pad/2), out-of-range = -INF, first max wins; indexes (may
+ * be NULL) = flat input index of the max. */
+DK_API int dk_maxpool_forward(const float* x, float* y, int* indexes, int batch, int c,
+    int h, int w, int size, int stride_x, int stride_y, int pad, void* stream);
+
+/* One source of ForwardRouteLayerGpu, src/route_layer.c:124-142: for every batch
+ * item copy part = input_size/groups floats from src + j*input_size +
+ * part*group_id to dst + offset + j*outputs (one launch for all batch items). */
+DK_API int dk_route_copy(const float* src, int input_size, int groups, int group_id,
+    int batch, float* dst, int outputs, int offset, void* stream);
+
+/* shortcut_singlelayer_simple_kernel, src/blas_kernels.cu:941-978 (n = 1, same
+ * shape) + activation: out = act(in + from). */
+DK_API int dk_shortcut_forward(const float* in, const float* from, float* out,
+    size_t total, int activation, void* stream);
+
+/* upsample_kernel forward, src/blas_kernels.cu:1121-1146: nearest x stride,
+ * out = scale * in (written once; no zero-fill + accumulate). */
+DK_API int dk_upsample_forward(const float* in, int w, int h, int c, int batch,
+    int stride, float scale, float* out, void* stream);
+
+/* ForwardYoloLayerGpu decode, src/yolo_layer.cpp:836-853, fused into one
+ * launch: copy; logistic on x,y then v*scale_x_y - 0.5*(scale_x_y-1);
+ * logistic on objectness and classes; w,h raw. */
+DK_API int dk_yolo_forward(const float* in, float* out, int batch, int lw, int lh,
+    int n_anchors, int classes, float scale_x_y, void* stream);
+
+/* activate_array_ongpu, src/activation_kernels.cu:505-560 (in place). */
+DK_API int dk_activate_array(float* x, size_t n, int activation, void* stream);
+/* activate_array_mish_ongpu, src/activation_kernels.cu:290-309, :577 */
+DK_API int dk_activate_array_mish(const float* x, size_t n, float* activation_input,
+    float* out, void* stream);
+/* add_bias_gpu / scale_bias_gpu, src/convolutional_kernels.cu:15-35,
+ * src/blas_kernels.cu:45-65 */
+DK_API int dk_add_bias(float* out, const float* biases, int batch, int n, int size, void* stream);
+DK_API int dk_scale_bias(float* out, const float* scales, int batch, int n, int size, void* stream);
+
+/* fill_ongpu / simple_copy_ongpu / axpy_ongpu / scal_ongpu,
+ * src/blas_kernels.cu:427-532 (unit strides only). */
+DK_API int dk_fill(size_t n, float alpha, float* x, void* stream);
+DK_API int dk_copy(size_t n, const float* x, float* y, void* stream);
+DK_API int dk_axpy(size_t n, float alpha, const float* x, float* y, void* stream);
+DK_API int dk_scal(size_t n, float alpha, float* x, void* stream);
+
+/* Profiling hooks used by bench.py (measurement only): when enabled every
+ * dk_conv_forward is bracketed by HIP events on its stream; dk_profile_read
+ * synchronises and returns per tile-configuration totals.
+ *   out[cfg*3+0] = launches, out[cfg*3+1] = algorithmic GFLOP
+ *   (2*nweights*oh*ow*batch/1e9, the reference's counter
+ *   src/convolutional_layer.cpp:714), out[cfg*3+2] = milliseconds. */
+DK_API void dk_profile_enable(int on);
+DK_API int dk_profile_read(double* out, int max_cfgs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DK_KERNELS_H */

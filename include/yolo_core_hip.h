@@ -1,0 +1,342 @@
+/*
+ * yolo_core_hip.h -- public network API of the MI355X-native Darknet conv path.
+ *
+ * Mirrors the reference's library surface for this path (Ravicmoon/darknet
+ * src/yolo_core.h:43-667, src/libapi.h, src/box.h, src/network.h, src/parser.h,
+ * src/convolutional_layer.h:7-18 ...): same function names, argument meaning,
+ * ownership and error behaviour (loaders return bool; everything else prints
+ * and exit()s), so a caller of lib_yolo_core recompiles against this header and
+ * relinks against libdarknet_amd.so.  Like the reference's header it is a C++
+ * header whose functions have C linkage names.
+ *
+ * `struct layer` / `Network` keep the reference's FIELD NAMES for everything the
+ * YOLOv4-family hot path touches (so `net->layers[i].out_w`, `l->output_gpu`,
+ * `l->forward_gpu` ... compile unchanged); fields that only serve subsystems
+ * outside the hot path (XNOR, cuDNN descriptors, dropout, local/connected
+ * layers, adam, data augmentation) do not exist here.  Binary layout is NOT the
+ * reference's: recompile, do not mix object files.  See INTEGRATION.md.
+ *
+ * Additive extensions (names starting with Dk or ending in Batch) exist because
+ * the reference forces batch = 1 for inference (src/parser.cpp:1114) and reads
+ * only batch item 0 when extracting detections (src/yolo_layer.cpp:786, :805).
+ */
+#ifndef YOLO_CORE_HIP_H
+#define YOLO_CORE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+#include <vector>
+#endif
+
+#ifndef LIB_API
+#define LIB_API __attribute__((visibility("default")))
+#endif
+
+#define SECRET_NUM -1234
+
+/* ---- enums (values identical to the reference) ------------------------- */
+typedef enum
+{ /* src/yolo_core.h:69-92 */
+  LOGISTIC, RELU, RELU6, RELIE, LINEAR, RAMP, TANH, PLSE, LEAKY, ELU, LOGGY,
+  STAIR, HARDTAN, LHTAN, SELU, GELU, SWISH, MISH, NORM_CHAN, NORM_CHAN_SOFTMAX,
+  NORM_CHAN_SOFTMAX_MAXVAL
+} ACTIVATION;
+
+typedef enum
+{ /* src/yolo_core.h:112-138 */
+  CONVOLUTIONAL, CONNECTED, MAXPOOL, LOCAL_AVGPOOL, DETECTION, DROPOUT, CROP,
+  ROUTE, COST, AVGPOOL, LOCAL, SHORTCUT, SCALE_CHANNELS, ACTIVE, BATCHNORM,
+  NETWORK, XNOR, YOLO, GAUSSIAN_YOLO, REORG, REORG_OLD, UPSAMPLE, EMPTY, BLANK
+} LAYER_TYPE;
+
+typedef enum { IOU, GIOU, MSE, DIOU, CIOU } IOU_LOSS;      /* src/box.h:6-13 */
+typedef enum { GREEDY_NMS, DIOU_NMS } NMS_KIND;            /* src/box.h:15-19 */
+typedef enum
+{ /* src/yolo_core.h:440-450 */
+  CONSTANT, STEP, EXP, POLY, STEPS, SIG, RANDOM, SGDR
+} LearningRatePolicy;
+
+/* ---- boxes / detections (src/box.h:33-97) ------------------------------ */
+#ifdef __cplusplus
+class LIB_API Box
+{
+ public:
+  Box() : x(0), y(0), w(0), h(0) {}
+  Box(float _x, float _y, float _w, float _h) : x(_x), y(_y), w(_w), h(_h) {}
+  static float Overlap(float x1, float w1, float x2, float w2);
+  static float Intersect(Box const& b1, Box const& b2);
+  static float Union(Box const& b1, Box const& b2);
+  static float Iou(Box const& b1, Box const& b2);
+  static float Diou(Box const& b1, Box const& b2, float beta = 0.6f);
+  float x, y, w, h;
+};
+#else
+typedef struct Box { float x, y, w, h; } Box;
+#endif
+
+typedef struct Detection
+{
+  Box bbox;          /* centre-normalised x, y, w, h */
+  int classes;
+  float* prob;       /* [classes] */
+  float* mask;
+  float objectness;
+  int sort_class;
+  float* uc;
+  int points;
+} Detection;
+
+typedef struct MostProbDet
+{
+  Box bbox;
+  int cid;
+  float prob;
+} MostProbDet;
+
+/* ---- layer / network (field names: src/yolo_core.h:149-558) ------------- */
+struct layer;
+typedef struct layer layer;
+struct Network;
+typedef struct Network Network;
+struct NetworkState;
+typedef struct NetworkState NetworkState;
+
+typedef struct NetworkState
+{
+  float* truth;
+  float* input;      /* device pointer on the *_gpu path */
+  float* delta;
+  float* workspace;
+  int train;
+  int index;
+  Network* net;
+} NetworkState;
+
+struct layer
+{
+  LAYER_TYPE type;
+  ACTIVATION activation;
+  /* plugin slots, src/yolo_core.h:154-159 */
+  void (*forward)(struct layer*, struct NetworkState);
+  void (*backward)(struct layer*, struct NetworkState);
+  void (*update)(struct layer*, int, float, float, float);
+  void (*forward_gpu)(struct layer*, struct NetworkState);
+  void (*backward_gpu)(struct layer*, struct NetworkState);
+  void (*update_gpu)(struct layer*, int, float, float, float, float);
+
+  layer* share_layer;
+  int train;
+  int batch_normalize;
+  int batch;
+  int steps;
+  int inputs, outputs;
+  int nweights, nbiases;
+  int truths;
+  int h, w, c;
+  int out_h, out_w, out_c;
+  int n;
+  int max_boxes;
+  int groups, group_id;
+  int size;
+  int stride, stride_x, stride_y;
+  int dilation;
+  int pad;
+  int index;
+  int reverse;
+  float scale;
+  float bflops;
+
+  /* yolo */
+  int classes, total;
+  int* mask;
+  float scale_x_y, max_delta, iou_normalizer, cls_normalizer, ignore_thresh,
+      truth_thresh, iou_thresh, jitter, random, label_smooth_eps, beta_nms;
+  int focal_loss;
+  float* classes_multipliers;
+  IOU_LOSS iou_loss, iou_thresh_kind;
+  NMS_KIND nms_kind;
+  int* map;
+
+  /* per-layer common keys, src/parser.cpp:1361-1369 */
+  float clip, learning_rate_scale;
+  int onlyforward, stopbackward, train_only_bn, dont_update, burnin_update,
+      dontload, dontloadscales;
+
+  /* route / shortcut */
+  int* input_layers;
+  int* input_sizes;
+
+  /* host tensors */
+  int* indexes;
+  float* cost;
+  float *biases, *bias_updates;
+  float *scales, *scale_updates;
+  float *weights, *weight_updates;
+  float *delta, *output, *activation_input;
+  int delta_pinned, output_pinned;
+  float *mean, *variance, *mean_delta, *variance_delta;
+  float *rolling_mean, *rolling_variance;
+  float *x, *x_norm;
+  size_t workspace_size;
+
+  /* device tensors */
+  int* indexes_gpu;
+  float *mean_gpu, *variance_gpu, *rolling_mean_gpu, *rolling_variance_gpu;
+  float *variance_delta_gpu, *mean_delta_gpu;
+  float *x_gpu, *x_norm_gpu;
+  float *weights_gpu, *weight_updates_gpu;
+  float *biases_gpu, *bias_updates_gpu;
+  float *scales_gpu, *scale_updates_gpu;
+  float *output_gpu, *activation_input_gpu, *delta_gpu;
+
+  /* MI355X-native additions */
+  int fused_into_prev;   /* shortcut folded into the previous conv's epilogue */
+  int fuse_residual_from; /* conv: layer index whose output is added in the epilogue, or -1 */
+  int conv_cfg;          /* tile configuration chosen by the autotuner, or -1 */
+};
+
+struct Network
+{
+  int max_epoch, max_iter;
+  int n;
+  int batch, subdiv;
+  uint64_t seen;
+  int curr_iter;
+  float loss_scale;
+  layer* layers;
+  float* output;
+  LearningRatePolicy policy;
+  int benchmark_layers;
+  float lr, lr_min;
+  int sgdr_cycle, sgdr_mult;
+  float momentum, decay, gamma, scale, power;
+  int step;
+  float *steps, *scales;
+  int num_steps;
+  int burn_in;
+  int cudnn_half;
+  int adam;
+  int inputs, outputs, truths;
+  int h, w, c;
+  int curr_subdiv;
+  int gpu_index;
+  float* input;
+  float* truth;
+  float* workspace;
+  int train;
+  float* cost;
+  float* input_state_gpu;
+  float* input_pinned_cpu;
+  int input_pinned_cpu_flag;
+  float** input_gpu;
+  float** truth_gpu;
+  int wait_stream;
+  size_t workspace_size_limit;
+
+  /* MI355X-native additions */
+  void* graph_exec;      /* hipGraphExec_t of the captured forward, or NULL */
+  int graph_batch;
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- loader: src/parser.cpp:1852-1876, :1076-1519, :1590-1643, :1778-1850 */
+LIB_API bool LoadNetwork(Network* net, char const* model_file,
+    char const* weights_file, bool train
+#ifdef __cplusplus
+    = false
+#endif
+    , bool clear
+#ifdef __cplusplus
+    = false
+#endif
+);
+LIB_API void FreeNetwork(Network* net);
+LIB_API bool ParseNetworkCfg(Network* net, char const* filename, bool train);
+LIB_API bool LoadWeights(Network* net, char const* filename);
+LIB_API bool LoadWeightsUpTo(Network* net, char const* filename, int cutoff);
+LIB_API void SaveWeights(Network* net, char const* filename);
+LIB_API void SaveWeightsUpto(Network* net, char const* filename, int cutoff);
+LIB_API void free_layer(layer* l, bool keep_cudnn_desc
+#ifdef __cplusplus
+    = false
+#endif
+);
+
+/* ---- graph engine: src/network.cpp:412-516, :647-682;
+ *      src/network_kernels.cu:45-114, :486-522 ------------------------------ */
+LIB_API float* NetworkPredict(Network* net, float* input);
+LIB_API Detection* GetNetworkBoxes(Network* net, float thresh, int* num);
+LIB_API Detection* MakeNetworkBoxes(Network* net, float thresh, int* num);
+LIB_API void FreeDetections(Detection* dets, int n);
+LIB_API void FuseConvBatchNorm(Network* net);
+LIB_API void ForwardNetworkGpu(Network* net, NetworkState state);
+LIB_API float* NetworkPredictGpu(Network* net, float* input);
+LIB_API float* GetNetworkOutputGpu(Network* net);
+LIB_API int GetNetworkInputSize(Network* net);
+LIB_API int GetNetworkOutputSize(Network* net);
+LIB_API float GetCurrLr(Network* net);
+
+/* ---- post-processing kept as host C++: src/box.cpp:372-447 --------------- */
+LIB_API void NmsSort(Detection* dets, int total, int classes, float thresh,
+    NMS_KIND nms_kind, float beta);
+
+/* ---- layer plugin entry points (the *_gpu slots), reference twins:
+ *      src/convolutional_kernels.cu:252-553, :817-863; src/maxpool_layer_kernels.cu
+ *      :145-240; src/route_layer.c:124-160; src/shortcut_layer.c:190-204;
+ *      src/upsample_layer.c:106-133; src/yolo_layer.cpp:836-888 ------------- */
+LIB_API void ForwardConvolutionalLayerGpu(layer* l, NetworkState state);
+LIB_API void PushConvolutionalLayer(layer* l);
+LIB_API void PullConvolutionalLayer(layer* l);
+LIB_API void add_bias_gpu(float* output, float* biases, int batch, int n, int size);
+LIB_API void ForwardMaxpoolLayerGpu(layer* l, NetworkState state);
+LIB_API void ForwardRouteLayerGpu(layer* l, NetworkState state);
+LIB_API void ForwardShortcutLayerGpu(layer* l, NetworkState state);
+LIB_API void ForwardUpsampleLayerGpu(layer* l, NetworkState state);
+LIB_API void ForwardYoloLayerGpu(layer* l, NetworkState state);
+LIB_API int YoloNumDetections(layer const* l, float thresh);
+LIB_API int GetYoloDetections(layer const* l, int net_w, int net_h, float thresh, Detection* dets);
+
+/* ---- additive extensions ----------------------------------------------- */
+/* Inference load with batch > 1 (BN folded exactly like LoadNetwork(train=false)). */
+LIB_API bool LoadNetworkBatch(Network* net, char const* model_file,
+    char const* weights_file, int batch);
+/* Forward from an input already resident in HBM (net->input_state_gpu when
+ * input_gpu == NULL); enqueues only, yolo heads are copied to pinned host
+ * memory asynchronously; NetworkSync() waits for them. */
+LIB_API void NetworkPredictDevice(Network* net, float* input_gpu);
+LIB_API void NetworkSync(Network* net);
+/* Batch-aware detection extraction (GetNetworkBoxes reads batch item 0). */
+LIB_API Detection* GetNetworkBoxesBatch(Network* net, int b, float thresh, int* num);
+/* Graph-level options: conv+shortcut epilogue fusion (default on for inference
+ * loads), hipGraph replay of the forward (default on), tile autotune at load. */
+LIB_API void DkSetFusion(int on);
+LIB_API void DkSetGraph(int on);
+LIB_API void DkSetAutotune(int on);
+
+/* Flat helpers for FFI callers (ctypes, tests, bench.py) */
+LIB_API Network* DkNetworkCreate(void);            /* calloc'ed Network */
+LIB_API void DkNetworkDestroy(Network* net);       /* FreeNetwork + free */
+LIB_API float* DkNetworkInputGpu(Network* net);
+LIB_API void DkNetworkInfo(Network* net, int* out /* [8]: n,batch,w,h,c,inputs,outputs,gpu_index */);
+LIB_API void DkLayerInfo(Network* net, int i, int* out /* [24], see tests/reflib.py INFO */);
+LIB_API float DkLayerBflops(Network* net, int i);
+LIB_API int DkLayerOutput(Network* net, int i, float* dst, size_t n); /* D2H copy of output_gpu */
+LIB_API float* DkLayerOutputGpu(Network* net, int i);
+LIB_API float* DkLayerHostPtr(Network* net, int i, int which); /* 1 weights 2 biases 3 scales 4 mean 5 var */
+/* Flattened detections of batch item b: per det [x,y,w,h,obj,prob[classes]] and
+ * ids [layer, anchor, row, col]; returns the count (writes at most max_dets). */
+LIB_API int DkGetBoxesBatch(Network* net, int b, float thresh, float* dets, int* ids, int max_dets);
+LIB_API size_t DkWeightsFileSize(Network* net);
+
+#ifdef __cplusplus
+}
+LIB_API std::vector<MostProbDet> GetMostProbDets(Detection* dets, int num_dets);
+#endif
+
+#endif /* YOLO_CORE_HIP_H */

@@ -1,0 +1,170 @@
+"""Whole-network parity on the MI355X, through the product's C-ABI network API:
+HIP path vs (a) the CPU oracle on the same seeded inputs, (b) the golden
+fixtures dumped from the real reference, (c) size-independent properties at the
+BASELINE.json sizes.  fp32 activations within util.REL (1e-4, util.py); detection
+box indices / class ids bit-exact at a guard-banded threshold."""
+import os
+
+import numpy as np
+import pytest
+
+import netutil
+import synth
+import util
+from oracle import orc_net as O
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def weights(gpu, tmp_path_factory):
+    d = tmp_path_factory.mktemp("w")
+    out = {}
+    for name in ("yolov4-tiny", "yolov4", "yolov4-csp"):
+        p = str(d / (name + ".weights"))
+        netutil.synth_weights_for(gpu, name, p)
+        out[name] = p
+    return out
+
+
+def check_dets(dets, ids, gdets, gids, what):
+    assert len(dets) == len(gdets), "%s: %d detections vs %d expected" % (what, len(dets), len(gdets))
+    assert np.array_equal(ids, gids), what + ": detection (layer, anchor, row, col) differ"
+    if len(dets):
+        assert np.array_equal(np.argmax(dets[:, 5:], 1), np.argmax(gdets[:, 5:], 1)), what + ": class ids differ"
+        util.assert_close(dets[:, :5], gdets[:, :5], what + " box/objectness")
+
+
+def test_tiny_b1_every_layer_vs_oracle_and_golden(gpu, weights):
+    name = "yolov4-tiny"
+    gpu.lib().DkSetFusion(0)
+    net = netutil.DkNet(gpu, netutil.cfg_path(name), weights[name])  # plain LoadNetwork: batch 1
+    assert net.batch == 1
+    onet = O.load_network(netutil.cfg_path(name), weights[name], batch=1)
+    x = synth.make_input(1, net.c, net.h, net.w)
+    net.predict(x)
+    O.forward(onet, x)
+    worst = 0.0
+    for i, l in enumerate(onet.layers):
+        st = util.assert_close(net.output(i), l.output, "%s layer %d" % (name, i))
+        worst = max(worst, st["max_abs_over_rms"])
+    print("worst max|d|/rms over layers: %.3g" % worst)
+    g = np.load(os.path.join(GOLD, "net_%s.npz" % name))
+    for i, l in enumerate(onet.layers):
+        if l.type == O.YOLO:
+            util.assert_close(net.output(i).ravel(), g["head_%d" % i], "golden head %d" % i)
+    thresh = float(g["thresh"])
+    dets, ids = net.boxes(0, thresh)
+    odets, oids = O.get_boxes(onet, thresh)
+    assert np.array_equal(oids, g["det_ids"])
+    check_dets(dets, ids, odets, oids, name)
+    net.close()
+    gpu.lib().DkSetFusion(1)
+
+
+def test_tiny_b4_batched_vs_oracle(gpu, weights):
+    name, B = "yolov4-tiny", 4
+    net = netutil.DkNet(gpu, netutil.cfg_path(name), weights[name], batch=B)
+    onet = O.load_network(netutil.cfg_path(name), weights[name], batch=B)
+    x = synth.make_input(B, net.c, net.h, net.w, seed=777)
+    net.predict(x)
+    O.forward(onet, x)
+    for i, l in enumerate(onet.layers):
+        if l.type == O.YOLO:
+            util.assert_close(net.output(i), l.output, "%s b%d head %d" % (name, B, i))
+    g = np.load(os.path.join(GOLD, "net_%s.npz" % name))
+    for b in range(B):
+        dets, ids = net.boxes(b, float(g["thresh"]))
+        odets, oids = O.get_boxes(onet, float(g["thresh"]), b=b)
+        # the golden threshold is guard-banded for the seed-12345 input only; for
+        # other inputs drop candidates inside the guard band before comparing ids
+        check_dets_guarded(dets, ids, odets, oids, float(g["thresh"]), "%s item %d" % (name, b))
+    net.close()
+
+
+def check_dets_guarded(dets, ids, odets, oids, thresh, what, guard=1e-3):
+    def key(i4):
+        return [tuple(r) for r in i4]
+    far_o = np.abs(odets[:, 4] - thresh) > guard
+    far_d = np.abs(dets[:, 4] - thresh) > guard
+    assert set(key(oids[far_o])) <= set(key(ids)), what + ": missing detections"
+    assert set(key(ids[far_d])) <= set(key(oids)), what + ": spurious detections"
+    common = {k: i for i, k in enumerate(key(oids))}
+    sel = [(i, common[k]) for i, k in enumerate(key(ids)) if k in common]
+    if sel:
+        a = np.array([s[0] for s in sel]); b = np.array([s[1] for s in sel])
+        util.assert_close(dets[a, :5], odets[b, :5], what + " box/objectness")
+        pa, pb = dets[a, 5:], odets[b, 5:]
+        clear = np.abs(np.sort(pb, 1)[:, -1] - np.sort(pb, 1)[:, -2]) > 1e-4
+        assert np.array_equal(np.argmax(pa, 1)[clear], np.argmax(pb, 1)[clear]), what + ": class ids differ"
+
+
+@pytest.mark.parametrize("name", ["yolov4", "yolov4-csp"])
+def test_big_nets_b1_vs_golden(gpu, weights, name):
+    """Fusion + graph + autotune on (the shipped configuration)."""
+    g = np.load(os.path.join(GOLD, "net_%s.npz" % name))
+    net = netutil.DkNet(gpu, netutil.cfg_path(name), weights[name])
+    assert net.n == int(g["n_layers"])
+    x = synth.make_input(1, net.c, net.h, net.w)
+    net.predict(x)
+    net.predict(x)  # second call replays the captured hipGraph
+    L = gpu.lib()
+    L.DkLayerFused.argtypes = [gpu.C.c_void_p, gpu.C.c_int]
+    nfused = 0
+    for i in range(net.n):
+        f = net.info(i)
+        if f["type"] == O.CONVOLUTIONAL and L.DkLayerFused(net.p, i):
+            nfused += 1
+            continue  # its own buffer is not written when folded into the shortcut
+        o = net.output(i).ravel()
+        idx = np.linspace(0, o.size - 1, 64).astype(np.int64)
+        ref = g["layer_samples"][i]
+        rms = np.sqrt(g["layer_sums"][i][1] / o.size)
+        err = np.abs(o[idx] - ref) / (util.REL * np.abs(ref) + util.ATOL_RMS * rms)
+        assert err.max() <= 1.0, "%s layer %d: sample err x%.3g over tolerance" % (name, i, err.max())
+        s = np.sum(o, dtype=np.float64)
+        assert abs(s - g["layer_sums"][i][0]) <= 1e-4 * max(abs(g["layer_sums"][i][0]), rms * np.sqrt(o.size)), \
+            "%s layer %d checksum" % (name, i)
+        if f["type"] == O.YOLO:
+            util.assert_close(o[::16], g["head_%d_sub16" % i], "%s head %d" % (name, i))
+    assert nfused > 0
+    dets, ids = net.boxes(0, float(g["thresh"]))
+    assert len(dets) == int(g["num_dets"])
+    assert np.array_equal(ids, g["det_ids"]), name + ": detection indices differ from the reference"
+    assert np.array_equal(np.argmax(dets[:, 5:], 1), g["det_best_class"]), name + ": class ids differ"
+    util.assert_close(dets[:, :5], g["det_box_obj"], name + " boxes")
+    net.close()
+
+
+def test_properties_at_baseline_size(gpu, weights):
+    """BASELINE config C3 (yolov4 608^2 b=16): batch-position invariance, eager ==
+    graph replay, fusion on == off -- all bitwise, and item 0 == the b=1 golden run."""
+    name, B = "yolov4", 16
+    L = gpu.lib()
+    g = np.load(os.path.join(GOLD, "net_%s.npz" % name))
+    x1 = synth.make_input(1, 3, 608, 608)
+    x = np.repeat(x1, B, 0)
+    net = netutil.DkNet(gpu, netutil.cfg_path(name), weights[name], batch=B)
+    heads = [i for i in range(net.n) if net.info(i)["type"] == O.YOLO]
+    net.predict(x)          # eager (first call)
+    a = [net.output(i) for i in heads]
+    net.predict(x)          # graph capture + replay
+    b = [net.output(i) for i in heads]
+    for u, v in zip(a, b):
+        assert np.array_equal(u, v), "graph replay differs from eager"
+        assert all(np.array_equal(u[0], u[k]) for k in range(1, B)), "output depends on batch position"
+    for i, u in zip(heads, a):
+        util.assert_close(u[0][::16], g["head_%d_sub16" % i], "b=16 item 0 vs golden head %d" % i)
+    dets, ids = net.boxes(B - 1, float(g["thresh"]))
+    assert np.array_equal(ids, g["det_ids"])
+    net.close()
+    L.DkSetFusion(0)
+    L.DkSetGraph(0)
+    net2 = netutil.DkNet(gpu, netutil.cfg_path(name), weights[name], batch=B)
+    net2.predict(x)
+    for i, u in zip(heads, a):
+        assert np.array_equal(net2.output(i), u), "fusion/graph off differs"
+    net2.close()
+    L.DkSetFusion(1)
+    L.DkSetGraph(1)

@@ -1,0 +1,181 @@
+"""Per-op parity: HIP kernels (through the C-ABI) vs the CPU oracle on the same
+seeded inputs.  fp32 activations within util.REL (1e-4, definition in util.py);
+integer outputs (maxpool argmax indexes) bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import util
+from oracle import orc_net as O
+
+pytestmark = pytest.mark.gpu
+
+F = C.c_float
+
+
+def orc_conv(x, w, bias, batch, c, h, wd, n, size, stride, pad, act, groups=1, dilation=1, stride_y=None):
+    L = O.lib()
+    sy = stride if stride_y is None else stride_y
+    keff = dilation * (size - 1) + 1
+    oh = (h + 2 * pad * dilation - keff) // sy + 1
+    ow = (wd + 2 * pad * dilation - keff) // stride + 1
+    out = np.zeros((batch, n, oh, ow), np.float32)
+    ws = np.zeros(max(1, oh * ow * size * size * (c // groups)), np.float32)
+    act_in = np.zeros_like(out)
+    L.orc_conv_forward_fused(O.fptr(x), O.fptr(w), O.fptr(bias), O.fptr(out), O.fptr(ws),
+                             O.fptr(act_in), batch, c, h, wd, n, groups, size, stride, sy,
+                             dilation, pad, act)
+    return out, act_in
+
+
+CONV_CASES = [
+    # batch, c, h, w, n, size, stride, pad, act, groups, dilation
+    (2, 3, 32, 32, 32, 3, 1, 1, "MISH", 1, 1),        # first layer shape class (K=27)
+    (2, 3, 33, 29, 32, 3, 2, 1, "LEAKY", 1, 1),       # stride 2, odd, non-square
+    (3, 32, 19, 19, 64, 3, 1, 1, "LEAKY", 1, 1),      # 19x19 (W not a multiple of anything)
+    (2, 64, 19, 19, 255, 1, 1, 0, "LINEAR", 1, 1),    # head: M=255 (ragged M), 1x1
+    (1, 128, 13, 13, 256, 1, 1, 0, "MISH", 1, 1),     # 1x1, N=169 < tile
+    (2, 64, 26, 26, 128, 3, 2, 1, "MISH", 1, 1),      # downsampler
+    (1, 16, 8, 8, 16, 1, 1, 0, "LOGISTIC", 1, 1),     # tiny everything (N=64, M=16)
+    (2, 32, 20, 20, 64, 3, 1, 1, "LEAKY", 2, 1),      # groups=2
+    (1, 8, 17, 17, 24, 3, 1, 1, "RELU", 1, 2),        # dilation 2 (cfg pad=1 -> l->pad=1, effective 2)
+    (2, 16, 14, 14, 32, 5, 1, 2, "LINEAR", 1, 1),     # 5x5
+    (1, 512, 19, 19, 1024, 3, 1, 1, "LEAKY", 1, 1),   # yolov4 neck shape, K=4608
+    (5, 4, 9, 7, 10, 3, 1, 1, "LINEAR", 1, 1),        # N spans image boundaries inside one tile
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_forward_vs_oracle(gpu, case):
+    batch, c, h, w, n, size, stride, pad, actname, groups, dil = case
+    act = getattr(O, actname) if hasattr(O, actname) else {"RELU": 1}[actname]
+    rng = np.random.default_rng(hash(case) & 0xFFFF)
+    x = rng.uniform(-1, 1, (batch, c, h, w)).astype(np.float32)
+    fan = size * size * c // groups
+    wt = (rng.uniform(-1, 1, (n, c // groups, size, size)) * np.sqrt(2.0 / fan)).astype(np.float32)
+    bias = rng.uniform(-.5, .5, n).astype(np.float32)
+    ref, _ = orc_conv(x, wt, bias, batch, c, h, w, n, size, stride, pad, act, groups, dil)
+    ref_in, _ = orc_conv(x, wt, bias, batch, c, h, w, n, size, stride, pad, O.LINEAR, groups, dil)
+    ncfg = gpu.lib().dk_conv_force_config(-1)
+    for cfg in [-1] + list(range(ncfg)):
+        gpu.lib().dk_conv_force_config(cfg)
+        y, act_in = gpu.conv_forward(x, wt, bias, batch, c, h, w, n, size, stride, pad, act,
+                                     groups=groups, dilation=dil, want_act_in=True)
+        util.assert_close(y, ref, "conv cfg %d %s" % (cfg, case))
+        util.assert_close(act_in, ref_in, "conv pre-activation cfg %d" % cfg)
+    gpu.lib().dk_conv_force_config(-1)
+
+
+def test_conv_identity_asymmetric(gpu):
+    """A = I check with an asymmetric B: catches a transposed C/D fragment map."""
+    c = n = 64
+    h, w = 8, 16
+    x = np.arange(c * h * w, dtype=np.float32).reshape(1, c, h, w) % 251
+    wt = np.eye(c, dtype=np.float32).reshape(n, c, 1, 1)
+    y = gpu.conv_forward(x, wt, np.zeros(n, np.float32), 1, c, h, w, n, 1, 1, 0, O.LINEAR)
+    assert np.array_equal(y, x)
+
+
+def test_conv_residual_and_nobias(gpu):
+    rng = np.random.default_rng(7)
+    batch, c, h, w, n = 2, 32, 19, 19, 32
+    x = rng.uniform(-1, 1, (batch, c, h, w)).astype(np.float32)
+    wt = (rng.uniform(-1, 1, (n, c, 3, 3)) * 0.08).astype(np.float32)
+    res = rng.uniform(-1, 1, (batch, n, h, w)).astype(np.float32)
+    ref, _ = orc_conv(x, wt, np.zeros(n, np.float32), batch, c, h, w, n, 3, 1, 1, O.LEAKY)
+    y = gpu.conv_forward(x, wt, None, batch, c, h, w, n, 3, 1, 1, O.LEAKY, residual=res)
+    util.assert_close(y, ref + res, "conv + residual")
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 26, 26, 2, 2, 1), (2, 6, 19, 19, 5, 1, 4), (1, 4, 19, 19, 9, 1, 8),
+                                   (3, 5, 19, 19, 13, 1, 12), (1, 3, 13, 11, 3, 2, 2), (1, 2, 7, 7, 2, 2, 0)])
+def test_maxpool_vs_oracle(gpu, shape):
+    batch, c, h, w, size, stride, pad = shape
+    rng = np.random.default_rng(1)
+    # quantised values -> many ties: exercises "first maximum wins"
+    x = np.round(rng.uniform(-4, 4, (batch, c, h, w))).astype(np.float32)
+    ow, oh = (w + pad - size) // stride + 1, (h + pad - size) // stride + 1
+    ref = np.zeros((batch, c, oh, ow), np.float32)
+    ridx = np.zeros((batch, c, oh, ow), np.int32)
+    O.lib().orc_maxpool_forward(O.fptr(x), O.fptr(ref), O.iptr(ridx), batch, c, h, w, size, stride, stride, pad)
+    dx = gpu.DeviceArray(x)
+    dy = gpu.DeviceArray(n=ref.size)
+    di = gpu.DeviceArray(n=ref.size, dtype=np.int32)
+    assert gpu.lib().dk_maxpool_forward(dx.ptr, dy.ptr, di.ptr, batch, c, h, w, size, stride, stride, pad, None) == 0
+    assert np.array_equal(dy.numpy().reshape(ref.shape), ref)
+    assert np.array_equal(di.numpy().reshape(ref.shape), ridx)
+
+
+def test_route_shortcut_upsample_yolo(gpu):
+    L, G = O.lib(), gpu.lib()
+    rng = np.random.default_rng(3)
+    batch = 3
+    # route: two sources, second with groups=2 group_id=1 semantics tested separately
+    a = rng.uniform(-1, 1, (batch, 6 * 5 * 5)).astype(np.float32)
+    b = rng.uniform(-1, 1, (batch, 4 * 5 * 5)).astype(np.float32)
+    for groups, gid in ((1, 0), (2, 1)):
+        outputs = (a.shape[1] + b.shape[1]) // groups
+        ref = np.zeros((batch, outputs), np.float32)
+        L.orc_route_copy(O.fptr(a), a.shape[1], groups, gid, batch, O.fptr(ref), outputs, 0)
+        L.orc_route_copy(O.fptr(b), b.shape[1], groups, gid, batch, O.fptr(ref), outputs, a.shape[1] // groups)
+        da, db, do = gpu.DeviceArray(a), gpu.DeviceArray(b), gpu.DeviceArray(n=ref.size)
+        assert G.dk_route_copy(da.ptr, a.shape[1], groups, gid, batch, do.ptr, outputs, 0, None) == 0
+        assert G.dk_route_copy(db.ptr, b.shape[1], groups, gid, batch, do.ptr, outputs, a.shape[1] // groups, None) == 0
+        assert np.array_equal(do.numpy().reshape(ref.shape), ref)
+    # shortcut (+ leaky)
+    for n in (1000, 1003):
+        p = rng.uniform(-1, 1, n).astype(np.float32)
+        q = rng.uniform(-1, 1, n).astype(np.float32)
+        for act in (O.LINEAR, O.LEAKY):
+            ref = np.zeros(n, np.float32)
+            L.orc_shortcut_forward(O.fptr(p), O.fptr(q), O.fptr(ref), n)
+            L.orc_activate_array(O.fptr(ref), n, act)
+            dp, dq, do = gpu.DeviceArray(p), gpu.DeviceArray(q), gpu.DeviceArray(n=n)
+            assert G.dk_shortcut_forward(dp.ptr, dq.ptr, do.ptr, n, act, None) == 0
+            assert np.array_equal(do.numpy(), ref)
+    # upsample x2 with scale
+    w, h, c = 7, 5, 3
+    u = rng.uniform(-1, 1, (batch, c, h, w)).astype(np.float32)
+    ref = np.zeros((batch, c, h * 2, w * 2), np.float32)
+    L.orc_upsample_forward(O.fptr(u), w, h, c, batch, 2, F(1.0), O.fptr(ref))
+    du, do = gpu.DeviceArray(u), gpu.DeviceArray(n=ref.size)
+    assert G.dk_upsample_forward(du.ptr, w, h, c, batch, 2, 1.0, do.ptr, None) == 0
+    assert np.array_equal(do.numpy().reshape(ref.shape), ref)
+    # yolo decode
+    lw, lh, na, classes = 13, 11, 3, 80
+    t = rng.uniform(-6, 6, (batch, na * (5 + classes) * lw * lh)).astype(np.float32)
+    for sxy in (1.0, 1.05, 2.0):
+        ref = np.zeros_like(t)
+        L.orc_yolo_forward(O.fptr(t), O.fptr(ref), batch, lw, lh, na, classes, F(sxy))
+        dt, do = gpu.DeviceArray(t), gpu.DeviceArray(n=t.size)
+        assert G.dk_yolo_forward(dt.ptr, do.ptr, batch, lw, lh, na, classes, sxy, None) == 0
+        util.assert_close(do.numpy().reshape(ref.shape), ref, "yolo decode sxy=%g" % sxy, rel=2e-6, atol_rms=1e-7)
+
+
+def test_activations_grid(gpu):
+    """leaky / mish / logistic on a fixed grid incl. the +-20 softplus thresholds."""
+    L, G = O.lib(), gpu.lib()
+    x = np.concatenate([np.linspace(-30, 30, 24001), [20.0, -20.0, 20.000002, -20.000002, 0.0, -0.0, 1e-30, -1e-30]]).astype(np.float32)
+    for act in (O.LEAKY, O.LOGISTIC):
+        ref = x.copy()
+        L.orc_activate_array(O.fptr(ref), ref.size, act)
+        d = gpu.DeviceArray(x)
+        assert G.dk_activate_array(d.ptr, x.size, act, None) == 0
+        got = d.numpy()
+        if act == O.LEAKY:
+            assert np.array_equal(got, ref)
+        else:
+            util.assert_close(got, ref, "logistic", rel=1e-6, atol_rms=1e-7)
+    ref = np.zeros_like(x)
+    ain = np.zeros_like(x)
+    L.orc_activate_array_mish(O.fptr(x), x.size, O.fptr(ain), O.fptr(ref))
+    d, da, do = gpu.DeviceArray(x), gpu.DeviceArray(n=x.size), gpu.DeviceArray(n=x.size)
+    assert G.dk_activate_array_mish(d.ptr, x.size, da.ptr, do.ptr, None) == 0
+    assert np.array_equal(da.numpy(), x)
+    got = do.numpy()
+    # The reference's mish formula logf(expf(x)+1) cancels catastrophically for
+    # x in [-16,-4]: a 1-ulp difference between glibc's and the device's expf can
+    # flip the rounding of (1+e^x), i.e. move softplus by 2^-23 and mish by up to
+    # |x| * 1.2e-7 ~ 2e-6 absolute.  Bar: 1e-4 relative + 2.5e-6 absolute.
+    assert np.all(np.abs(got - ref) <= 1e-4 * np.abs(ref) + 2.5e-6)

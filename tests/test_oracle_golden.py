@@ -1,0 +1,126 @@
+"""CPU: the oracle restatement (oracle/orc_ops.c + orc_net.py) against the golden
+fixtures dumped from the REAL reference (tools/make_golden.py).  Bit-exact."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import synth
+from oracle import orc_net as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F = C.c_float
+
+
+@pytest.fixture(scope="module")
+def ops():
+    return np.load(os.path.join(GOLD, "ops.npz"))
+
+
+def test_im2col_col2im(ops):
+    L = O.lib()
+    for i, (c, h, w, kh, kw, ph, pw, sh, sw, dh, dw) in enumerate(ops["im2col_cases"]):
+        c, h, w, kh, kw, ph, pw, sh, sw, dh, dw = map(int, (c, h, w, kh, kw, ph, pw, sh, sw, dh, dw))
+        im = np.ascontiguousarray(ops[f"im2col_{i}_im"])
+        col = np.zeros_like(ops[f"im2col_{i}_col"])
+        L.orc_im2col_ext(O.fptr(im), c, h, w, kh, kw, ph, pw, sh, sw, dh, dw, O.fptr(col))
+        assert np.array_equal(col, ops[f"im2col_{i}_col"])
+        cin = np.ascontiguousarray(ops[f"col2im_{i}_col"])
+        back = np.full((c, h, w), 7.0, np.float32)
+        L.orc_col2im_ext(O.fptr(cin), c, h, w, kh, kw, ph, pw, sh, sw, dh, dw, O.fptr(back))
+        assert np.array_equal(back, ops[f"col2im_{i}_im"])
+
+
+def test_gemm(ops):
+    L = O.lib()
+    for i, (ta, tb, m, n, k) in enumerate(ops["gemm_cases"]):
+        alpha, beta = ops["gemm_alpha_beta"][i]
+        A = np.ascontiguousarray(ops[f"gemm_{i}_A"])
+        B = np.ascontiguousarray(ops[f"gemm_{i}_B"])
+        Cm = ops[f"gemm_{i}_C0"].copy()
+        L.orc_gemm(int(ta), int(tb), int(m), int(n), int(k), F(alpha), O.fptr(A), A.shape[1],
+                   O.fptr(B), B.shape[1], F(beta), O.fptr(Cm), int(n))
+        assert np.array_equal(Cm, ops[f"gemm_{i}_C"]), i
+
+
+def test_activations(ops):
+    L = O.lib()
+    g = ops["act_grid"]
+    for name, a in (("leaky", O.LEAKY), ("logistic", O.LOGISTIC), ("relu", O.RELU)):
+        x = g.copy()
+        L.orc_activate_array(O.fptr(x), x.size, a)
+        assert np.array_equal(x, ops["act_" + name]), name
+    y = np.zeros_like(g)
+    ain = np.zeros_like(g)
+    L.orc_activate_array_mish(O.fptr(g.copy()), g.size, O.fptr(ain), O.fptr(y))
+    assert np.array_equal(y, ops["act_mish"]) and np.array_equal(ain, ops["act_mish_input"])
+    d = np.ones_like(g)
+    L.orc_gradient_array_mish(g.size, O.fptr(g.copy()), O.fptr(d))
+    assert np.array_equal(d, ops["grad_mish"])
+    for name, a in (("leaky", O.LEAKY), ("logistic", O.LOGISTIC)):
+        d = np.ones_like(g)
+        L.orc_gradient_array(O.fptr(np.ascontiguousarray(ops["act_" + name])), g.size, a, O.fptr(d))
+        assert np.array_equal(d, ops["grad_" + name])
+
+
+def test_bn_statistics(ops):
+    L = O.lib()
+    x = np.ascontiguousarray(ops["bn_x"])
+    mean = np.zeros(5, np.float32)
+    var = np.zeros(5, np.float32)
+    L.orc_mean(O.fptr(x), 3, 5, 42, O.fptr(mean))
+    L.orc_variance(O.fptr(x), O.fptr(mean), 3, 5, 42, O.fptr(var))
+    xn = x.copy()
+    L.orc_normalize(O.fptr(xn), O.fptr(mean), O.fptr(var), 3, 5, 42)
+    assert np.array_equal(mean, ops["bn_mean"])
+    assert np.array_equal(var, ops["bn_var"])
+    assert np.array_equal(xn, ops["bn_norm"])
+
+
+def test_maxpool_with_indexes():
+    g = np.load(os.path.join(GOLD, "maxpool.npz"))
+    L = O.lib()
+    x = np.ascontiguousarray(g["x"])
+    for i, (size, stride) in enumerate(g["cases"]):
+        size, stride = int(size), int(stride)
+        pad = size - 1
+        ow = (19 + pad - size) // stride + 1
+        y = np.zeros(6 * ow * ow, np.float32)
+        idx = np.zeros(6 * ow * ow, np.int32)
+        L.orc_maxpool_forward(O.fptr(x), O.fptr(y), O.iptr(idx), 1, 6, 19, 19, size, stride, stride, pad)
+        assert np.array_equal(y, g[f"y_{i}"]) and np.array_equal(idx, g[f"idx_{i}"]), (size, stride)
+
+
+@pytest.mark.parametrize("name", ["yolov4-tiny", "yolov4-csp", "yolov4"])
+def test_whole_net_inference(name, tmp_path):
+    g = np.load(os.path.join(GOLD, f"net_{name}.npz"))
+    cfg = os.path.join(ROOT, "cfg", name + ".cfg")
+    net = O.parse_cfg(cfg)
+    assert net.n == int(g["n_layers"])
+    convs = [(l.n, l.c // l.groups, l.size, l.batch_normalize) for l in net.layers if l.type == O.CONVOLUTIONAL]
+    wpath = str(tmp_path / "w.weights")
+    synth.write_weights(wpath, convs, seed=2024)
+    assert os.path.getsize(wpath) == int(g["weights_bytes"]) == O.weights_file_size(net)
+    net = O.load_network(cfg, wpath, batch=1)
+    x = synth.make_input(1, net.c, net.h, net.w, seed=12345)
+    O.forward(net, x)
+    for i, l in enumerate(net.layers):
+        o = l.output.ravel()
+        assert l.type == g["layer_types"][i] and l.outputs == g["layer_outputs"][i]
+        idx = np.linspace(0, o.size - 1, 64).astype(np.int64)
+        assert np.array_equal(o[idx], g["layer_samples"][i]), f"layer {i} samples"
+        assert np.sum(o, dtype=np.float64) == g["layer_sums"][i][0], f"layer {i} sum"
+        assert np.sum(o.astype(np.float64) ** 2) == g["layer_sums"][i][1], f"layer {i} sum of squares"
+        if l.type == O.YOLO:
+            if f"head_{i}" in g:
+                assert np.array_equal(o, g[f"head_{i}"])
+            else:
+                assert np.array_equal(o[::16], g[f"head_{i}_sub16"])
+    dets, ids = O.get_boxes(net, float(g["thresh"]))
+    assert len(dets) == int(g["num_dets"])
+    assert np.array_equal(ids, g["det_ids"])
+    assert np.array_equal(dets[:, :5], g["det_box_obj"])
+    assert np.array_equal(np.argmax(dets[:, 5:], 1), g["det_best_class"])
+    assert np.array_equal(np.max(dets[:, 5:], 1), g["det_best_prob"])

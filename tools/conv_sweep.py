@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Dev tool (GPU box): time every compiled tile configuration of the implicit-GEMM
+conv kernel on each distinct conv shape of a cfg and print the table.
+usage: conv_sweep.py cfg/yolov4.cfg BATCH [iters]"""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import darknet_amd as dk  # noqa: E402
+from oracle import orc_net as O  # noqa: E402  (shape parsing only; dev tool)
+
+
+def main():
+    cfg, batch = sys.argv[1], int(sys.argv[2])
+    iters = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+    L = dk.lib()
+    L.cuda_set_device(0)
+    net = O.parse_cfg(cfg, batch=batch)
+    shapes = {}
+    for l in net.layers:
+        if l.type != O.CONVOLUTIONAL:
+            continue
+        key = (l.c, l.h, l.w, l.n, l.size, l.stride_x, l.pad, l.activation, l.groups)
+        shapes.setdefault(key, []).append(l.index)
+    ncfg = L.dk_conv_force_config(-1)
+    names = [L.dk_conv_config_name(i).decode() for i in range(ncfg)]
+    rows = []
+    tot_best = tot_heur = 0.0
+    tot_gflop = 0.0
+    maxin = max(batch * k[0] * k[1] * k[2] for k in shapes)
+    maxout = max(batch * l.outputs for l in net.layers if l.type == O.CONVOLUTIONAL)
+    rng = np.random.default_rng(0)
+    dx = dk.DeviceArray(rng.uniform(-1, 1, maxin).astype(np.float32))
+    dy = dk.DeviceArray(n=maxout)
+    for key, idxs in sorted(shapes.items(), key=lambda kv: kv[1][0]):
+        c, h, w, n, size, stride, pad, act, groups = key
+        d = dk.DkConvDesc(batch, c, h, w, n, groups, size, stride, stride, 1, pad, act)
+        wt = dk.DeviceArray((rng.uniform(-1, 1, n * (c // groups) * size * size) * 0.05).astype(np.float32))
+        bs = dk.DeviceArray(rng.uniform(-1, 1, n).astype(np.float32))
+        L.dk_conv_force_config(-1)
+        heur = L.dk_conv_pick_config(C.byref(d))
+        times = []
+        for cfgi in range(ncfg):
+            L.dk_conv_force_config(cfgi)
+            L.dk_conv_forward(C.byref(d), dx.ptr, wt.ptr, bs.ptr, dy.ptr, None, None, None)  # warm
+            L.dk_profile_enable(1)
+            for _ in range(iters):
+                L.dk_conv_forward(C.byref(d), dx.ptr, wt.ptr, bs.ptr, dy.ptr, None, None, None)
+            out = (C.c_double * (3 * 16))()
+            L.dk_profile_read(out, 16)
+            L.dk_profile_enable(0)
+            ms = out[cfgi * 3 + 2] / iters
+            gf = out[cfgi * 3 + 1] / iters
+            times.append(ms)
+        best = int(np.argmin(times))
+        cnt = len(idxs)
+        tot_best += times[best] * cnt
+        tot_heur += times[heur] * cnt
+        tot_gflop += gf * cnt
+        rows.append(dict(layers=idxs, shape=key, gflop=gf, ms=times, best=best, heur=heur,
+                         tf_best=gf / times[best], tf_heur=gf / times[heur]))
+        print("L%-4d x%-2d c%-4d %3dx%-3d n%-4d k%d s%d  GF %7.2f | " % (idxs[0], cnt, c, h, w, n, size, stride, gf) +
+              " ".join("%6.3f" % t for t in times) + " | best %d (%5.1f TF) heur %d (%5.1f TF)" %
+              (best, gf / times[best], heur, gf / times[heur]), flush=True)
+        wt.free(); bs.free()
+    L.dk_conv_force_config(-1)
+    print("configs:", names)
+    print("total conv GFLOP %.1f  best-per-layer %.3f ms (%.1f TF)  heuristic %.3f ms (%.1f TF)" %
+          (tot_gflop, tot_best, tot_gflop / tot_best, tot_heur, tot_gflop / tot_heur))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "conv_sweep_%s_b%d.json" % (os.path.basename(cfg), batch)), "w") as f:
+        json.dump(dict(names=names, rows=rows), f)
+
+
+if __name__ == "__main__":
+    main()

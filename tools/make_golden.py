@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ from the REAL reference.
+
+Runs only in the build container (needs oracle/_ref/libref_canon.so, i.e. the
+reference's own CPU sources compiled unmodified by oracle/Makefile, canonical
+build: -O2 -ffp-contract=off, scalar branches).  The fixtures are data only:
+inputs, seeds and the reference's outputs -- never reference source text.
+
+  ops.npz            per-op vectors: im2col/col2im on odd shapes, gemm NN/NT/TN/TT,
+                     activations on a fixed grid (incl. the +-20 softplus
+                     thresholds), maxpool 2/2 and SPP 5,9,13/1 at 19x19 with
+                     indexes, BN statistics, one fused-BN layer, yolo decode.
+  net_<cfg>.npz      whole-net inference (b=1, synthetic weights seed 2024, input
+                     seed 12345): per-layer sum / sum-of-squares / 64 strided
+                     samples, the full decoded yolo heads (tiny) or a 1/16
+                     subsample (yolov4, csp), and the detection list at a
+                     guard-banded threshold (box fields, objectness, ids).
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import reflib  # noqa: E402
+import synth  # noqa: E402
+from oracle import orc_net as O  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+FP = C.POINTER(C.c_float)
+IPT = C.POINTER(C.c_int)
+
+
+def fp(a):
+    return a.ctypes.data_as(FP)
+
+
+def ip(a):
+    return a.ctypes.data_as(IPT)
+
+
+def gen_ops():
+    L = reflib.lib("canon")
+    rng = np.random.default_rng(20240601)
+    out = {}
+    # ---- im2col / col2im (Caffe-style ext, pad/stride/dilation, odd shapes)
+    cases = [(3, 7, 9, 3, 3, 1, 1, 1, 1, 1, 1), (2, 8, 5, 3, 3, 1, 1, 2, 2, 1, 1),
+             (4, 9, 9, 3, 3, 2, 2, 1, 1, 2, 2), (1, 6, 11, 5, 5, 2, 2, 1, 2, 1, 1),
+             (5, 4, 4, 1, 1, 0, 0, 1, 1, 1, 1), (2, 10, 7, 3, 3, 0, 0, 3, 2, 1, 1)]
+    out["im2col_cases"] = np.array(cases, np.int32)
+    for i, (c, h, w, kh, kw, ph, pw, sh, sw, dh, dw) in enumerate(cases):
+        im = rng.uniform(-1, 1, (c, h, w)).astype(np.float32)
+        oh = (h + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1
+        ow = (w + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
+        col = np.zeros((c * kh * kw, oh * ow), np.float32)
+        L.im2col_cpu_ext(fp(im), c, h, w, kh, kw, ph, pw, sh, sw, dh, dw, fp(col))
+        cin = rng.uniform(-1, 1, col.shape).astype(np.float32)
+        back = np.full((c, h, w), 7.0, np.float32)
+        L.col2im_cpu_ext(fp(cin), c, h, w, kh, kw, ph, pw, sh, sw, dh, dw, fp(back))
+        out[f"im2col_{i}_im"], out[f"im2col_{i}_col"] = im, col
+        out[f"col2im_{i}_col"], out[f"col2im_{i}_im"] = cin, back
+    # ---- gemm (gemm_cpu, all four transposes, beta 1 and 0)
+    L.gemm_cpu.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, FP, C.c_int,
+                           FP, C.c_int, C.c_float, FP, C.c_int]
+    gcases = [(0, 0, 7, 13, 27, 1.0, 1.0), (0, 1, 5, 9, 31, 1.0, 1.0), (1, 0, 9, 11, 6, 1.0, 0.0),
+              (1, 1, 4, 6, 10, 1.0, 1.0), (0, 0, 32, 169, 288, 1.0, 1.0), (0, 0, 3, 5, 4, 0.5, 2.0)]
+    out["gemm_cases"] = np.array([(a, b, m, n, k) for a, b, m, n, k, _, _ in gcases], np.int32)
+    out["gemm_alpha_beta"] = np.array([(al, be) for *_, al, be in gcases], np.float32)
+    for i, (ta, tb, m, n, k, alpha, beta) in enumerate(gcases):
+        A = rng.uniform(-1, 1, (k, m) if ta else (m, k)).astype(np.float32)
+        B = rng.uniform(-1, 1, (n, k) if tb else (k, n)).astype(np.float32)
+        Cm = rng.uniform(-1, 1, (m, n)).astype(np.float32)
+        C0 = Cm.copy()
+        L.gemm_cpu(ta, tb, m, n, k, alpha, fp(A), A.shape[1], fp(B), B.shape[1], beta, fp(Cm), n)
+        out[f"gemm_{i}_A"], out[f"gemm_{i}_B"], out[f"gemm_{i}_C0"], out[f"gemm_{i}_C"] = A, B, C0, Cm
+    # ---- activations on a fixed grid
+    grid = np.concatenate([np.linspace(-30, 30, 6001),
+                           [20.0, -20.0, 20.000002, -20.000002, 19.999998, -19.999998, 0.0, 1e-30]]).astype(np.float32)
+    out["act_grid"] = grid
+    L.activate_array_cpu_custom.argtypes = [FP, C.c_int, C.c_int]
+    for name, a in (("leaky", O.LEAKY), ("logistic", O.LOGISTIC), ("relu", O.RELU)):
+        x = grid.copy()
+        L.activate_array_cpu_custom(fp(x), x.size, a)
+        out["act_" + name] = x
+    x = grid.copy()
+    ain = np.zeros_like(x)
+    y = np.zeros_like(x)
+    L.activate_array_mish(fp(x), x.size, fp(ain), fp(y))
+    out["act_mish"], out["act_mish_input"] = y, ain
+    d = np.ones_like(grid)
+    L.gradient_array_mish(grid.size, fp(grid), fp(d))
+    out["grad_mish"] = d
+    for name, a in (("leaky", O.LEAKY), ("logistic", O.LOGISTIC)):
+        d = np.ones_like(grid)
+        yv = out["act_" + name]
+        L.gradient_array(fp(yv), grid.size, a, fp(d))
+        out["grad_" + name] = d
+    # ---- maxpool via the public layer path of the reference net (cfg below)
+    # ---- BN statistics
+    xb = rng.uniform(-2, 2, (3, 5, 7 * 6)).astype(np.float32)
+    mean = np.zeros(5, np.float32)
+    var = np.zeros(5, np.float32)
+    getattr(L, "_Z8mean_cpuPfiiiS_")(fp(xb), 3, 5, 42, fp(mean))
+    getattr(L, "_Z12variance_cpuPfS_iiiS_")(fp(xb), fp(mean), 3, 5, 42, fp(var))
+    xn = xb.copy()
+    getattr(L, "_Z13normalize_cpuPfS_S_iii")(fp(xn), fp(mean), fp(var), 3, 5, 42)
+    out["bn_x"], out["bn_mean"], out["bn_var"], out["bn_norm"] = xb, mean, var, xn
+    np.savez_compressed(os.path.join(GOLD, "ops.npz"), **out)
+    print("ops.npz:", len(out), "arrays")
+
+
+MAXPOOL_CFG = """[net]
+batch=1
+subdivisions=1
+width=19
+height=19
+channels=6
+[maxpool]
+size={size}
+stride={stride}
+"""
+
+
+def gen_maxpool():
+    """maxpool through the reference's train-mode generic loop (definition-correct,
+    SURVEY quirk 5) incl. argmax indexes."""
+    rng = np.random.default_rng(5)
+    out = {}
+    cases = [(2, 2), (5, 1), (9, 1), (13, 1), (3, 2)]
+    out["cases"] = np.array(cases, np.int32)
+    x = np.round(rng.uniform(-4, 4, (1, 6 * 19 * 19))).astype(np.float32)
+    out["x"] = x
+    for i, (size, stride) in enumerate(cases):
+        path = "/tmp/_dk_maxpool.cfg"
+        with open(path, "w") as f:
+            f.write(MAXPOOL_CFG.format(size=size, stride=stride))
+        rn = reflib.RefNet(path, None, train=True)
+        rn.L.ref_forward_train(rn.p, fp(x), None)
+        inf = rn.info(0)
+        out[f"y_{i}"] = rn.output(0)
+        idx = rn.L.ref_layer_indexes(rn.p, 0)
+        out[f"idx_{i}"] = np.ctypeslib.as_array(idx, shape=(inf["outputs"],)).copy()
+        rn.close()
+    np.savez_compressed(os.path.join(GOLD, "maxpool.npz"), **out)
+    print("maxpool.npz")
+
+
+def pick_threshold(obj, lo=0.3, hi=0.7, guard=2e-3):
+    """A detection threshold with no objectness/probability within `guard` of it."""
+    v = np.sort(obj[(obj > lo) & (obj < hi)])
+    if v.size == 0:
+        return 0.5
+    edges = np.concatenate([[lo], v, [hi]])
+    gaps = np.diff(edges)
+    i = int(np.argmax(gaps))
+    assert gaps[i] > 2 * guard, "no gap wide enough for a guard-banded threshold"
+    return float(np.float32((edges[i] + edges[i + 1]) / 2))
+
+
+def gen_net(name, full_heads):
+    cfg = os.path.join(ROOT, "cfg", name + ".cfg")
+    net = O.parse_cfg(cfg)
+    convs = [(l.n, l.c // l.groups, l.size, l.batch_normalize) for l in net.layers
+             if l.type == O.CONVOLUTIONAL]
+    wpath = f"/tmp/_dk_{name}.weights"
+    synth.write_weights(wpath, convs, seed=2024)
+    x = synth.make_input(1, net.c, net.h, net.w, seed=12345)
+    rn = reflib.RefNet(cfg, wpath, train=False)
+    rn.predict(x)
+    out = {"n_layers": np.int32(rn.n), "weights_bytes": np.int64(os.path.getsize(wpath))}
+    sums, samples, types, outs = [], [], [], []
+    heads = {}
+    for i in range(rn.n):
+        o = rn.output(i)
+        inf = rn.info(i)
+        types.append(inf["type"])
+        outs.append(inf["outputs"])
+        sums.append((np.sum(o, dtype=np.float64), np.sum(o.astype(np.float64) ** 2)))
+        idx = np.linspace(0, o.size - 1, 64).astype(np.int64)
+        samples.append(o[idx])
+        if inf["type"] == O.YOLO:
+            heads[i] = o
+    out["layer_types"] = np.array(types, np.int32)
+    out["layer_outputs"] = np.array(outs, np.int64)
+    out["layer_sums"] = np.array(sums, np.float64)
+    out["layer_samples"] = np.array(samples, np.float32)
+    allobj = []
+    for i, o in heads.items():
+        inf = rn.info(i)
+        if full_heads:
+            out[f"head_{i}"] = o
+        else:
+            out[f"head_{i}_sub16"] = o[::16].copy()
+        wh = inf["out_h"] * inf["out_w"]
+        v = o.reshape(3, 5 + inf["classes"], wh)
+        allobj.append(v[:, 4, :].ravel())
+        allobj.append((v[:, 4:5, :] * v[:, 5:, :]).ravel())
+    thresh = pick_threshold(np.concatenate(allobj))
+    dets = rn.boxes(thresh)
+    out["thresh"] = np.float32(thresh)
+    out["num_dets"] = np.int32(len(dets))
+    # ids (layer, anchor, row, col) + best class, from the oracle (bit-identical
+    # to the reference; asserted here)
+    onet = O.load_network(cfg, wpath, batch=1)
+    O.forward(onet, x)
+    od, oid = O.get_boxes(onet, thresh)
+    assert np.array_equal(od, dets), "oracle and reference detections differ"
+    for i, l in enumerate(onet.layers):
+        assert np.array_equal(l.output.ravel(), rn.output(i)), f"oracle != reference at layer {i}"
+    out["det_ids"] = oid
+    out["det_box_obj"] = dets[:, :5].copy()
+    out["det_best_class"] = np.argmax(dets[:, 5:], 1).astype(np.int32) if len(dets) else np.zeros(0, np.int32)
+    out["det_best_prob"] = np.max(dets[:, 5:], 1) if len(dets) else np.zeros(0, np.float32)
+    out["det_nonzero_classes"] = np.count_nonzero(dets[:, 5:], 1).astype(np.int32)
+    rn.close()
+    np.savez_compressed(os.path.join(GOLD, f"net_{name}.npz"), **out)
+    print(f"net_{name}.npz: layers {rn.n}, dets {len(dets)} at thresh {thresh:.6f}")
+
+
+def main():
+    assert reflib.available("canon"), "build oracle/_ref first: make -C oracle ref"
+    os.makedirs(GOLD, exist_ok=True)
+    gen_ops()
+    gen_maxpool()
+    gen_net("yolov4-tiny", full_heads=True)
+    gen_net("yolov4", full_heads=False)
+    gen_net("yolov4-csp", full_heads=False)
+
+
+if __name__ == "__main__":
+    main()
