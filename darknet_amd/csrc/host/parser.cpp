@@ -435,7 +435,7 @@ static void SaveConvolutionalWeights(layer* l, FILE* fp)
 
 void SaveWeightsUpto(Network* net, char const* filename, int cutoff)
 {
-  if (net->gpu_index >= 0)
+  if (net->gpu_index >= 0 && net->layers && dk_gpu_enabled())
     cuda_set_device(net->gpu_index);
   FILE* fp = fopen(filename, "wb");
   if (!fp)
@@ -483,7 +483,7 @@ static void LoadConvolutionalWeights(layer* l, FILE* fp)
 
 bool LoadWeightsUpTo(Network* net, char const* filename, int cutoff)
 {
-  if (net->gpu_index >= 0)
+  if (net->gpu_index >= 0 && net->layers && dk_gpu_enabled())
     cuda_set_device(net->gpu_index);
   FILE* fp = fopen(filename, "rb");
   if (fp == nullptr)

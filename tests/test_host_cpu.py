@@ -1,0 +1,162 @@
+"""CPU (no GPU): the C-ABI library loads and exports every symbol include/*.h
+declares; the loader (cfg parser, .weights reader/writer, BN folding) and the host
+post-processing (NmsSort) match the oracle / golden fixtures; compute entry points
+fail loudly without a device."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import netutil
+import synth
+from oracle import orc_net as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def declared_symbols():
+    names = set()
+    for h in ("dk_kernels.h", "dark_hip.h", "yolo_core_hip.h"):
+        txt = open(os.path.join(ROOT, "include", h)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        for m in re.finditer(r"(?:DK_API|LIB_API)\s+[\w\s\*:<>]+?\b(\w+)\s*\(", txt):
+            names.add(m.group(1))
+    names.discard("Box")
+    return sorted(names)
+
+
+def test_every_declared_symbol_is_exported(dk):
+    L = dk.lib()
+    syms = declared_symbols()
+    assert len(syms) > 70
+    missing = []
+    for s in syms:
+        if s == "GetMostProbDets":  # C++ linkage (returns std::vector), checked via nm below
+            continue
+        try:
+            getattr(L, s)
+        except AttributeError:
+            missing.append(s)
+    assert not missing, "declared in include/*.h but not exported: %s" % missing
+    nm = subprocess.run(["nm", "-D", "--defined-only", dk.LIB_PATH], stdout=subprocess.PIPE).stdout.decode()
+    assert "GetMostProbDets" in nm
+    # no torch / CUDA types in the boundary
+    for h in os.listdir(os.path.join(ROOT, "include")):
+        incs = re.findall(r"^\s*#\s*include\s*[<\"]([^>\"]+)", open(os.path.join(ROOT, "include", h)).read(), flags=re.M)
+        for inc in incs:
+            assert not re.search(r"torch|cuda|cublas|cudnn|curand|ATen", inc), (h, inc)
+
+
+@pytest.mark.parametrize("name,layers,bflops,wbytes", [("yolov4-tiny", 38, 6.910, 24251276),
+                                                       ("yolov4", 162, 128.459, 257717640),
+                                                       ("yolov4-csp", 175, 77.003, 211944840)])
+def test_parser_invariants(dk, name, layers, bflops, wbytes):
+    """The format invariants of SURVEY.md section 4 + layer table == the oracle's."""
+    L = dk.lib()
+    L.ParseNetworkCfg.restype = C.c_bool
+    L.ParseNetworkCfg.argtypes = [C.c_void_p, C.c_char_p, C.c_bool]
+    p = L.DkNetworkCreate()
+    assert L.ParseNetworkCfg(p, netutil.cfg_path(name).encode(), False)
+    a = (C.c_int * 8)()
+    L.DkNetworkInfo(p, a)
+    assert a[0] == layers and a[1] == 1 and a[7] == -1  # inference forces batch 1; no device
+    assert L.DkWeightsFileSize(p) == wbytes
+    tot = np.float32(0)
+    onet = O.parse_cfg(netutil.cfg_path(name))
+    for i in range(a[0]):
+        f = (C.c_int * 24)()
+        L.DkLayerInfo(p, i, f)
+        b = np.float32(L.DkLayerBflops(p, i))
+        if b > 0:
+            tot = np.float32(tot + b)
+        ol = onet.layers[i]
+        assert (f[0], f[2], f[3], f[4], f[5]) == (ol.type, ol.outputs, ol.out_c, ol.out_h, ol.out_w), i
+    assert "%.3f" % tot == "%.3f" % bflops
+    L.DkNetworkDestroy(p)
+
+
+def test_weights_roundtrip_and_bn_folding(dk, tmp_path):
+    name = "yolov4-tiny"
+    L = dk.lib()
+    w = str(tmp_path / "a.weights")
+    convs = netutil.synth_weights_for(dk, name, w)
+    onet = O.parse_cfg(netutil.cfg_path(name))
+    assert convs == [(l.n, l.c // l.groups, l.size, l.batch_normalize) for l in onet.layers if l.type == O.CONVOLUTIONAL]
+    # un-fused: LoadWeights + SaveWeights reproduces the file byte for byte
+    L.ParseNetworkCfg.restype = C.c_bool
+    L.ParseNetworkCfg.argtypes = [C.c_void_p, C.c_char_p, C.c_bool]
+    L.LoadWeights.restype = C.c_bool
+    L.LoadWeights.argtypes = [C.c_void_p, C.c_char_p]
+    p = L.DkNetworkCreate()
+    assert L.ParseNetworkCfg(p, netutil.cfg_path(name).encode(), False)
+    assert L.LoadWeights(p, w.encode())
+    w2 = str(tmp_path / "b.weights")
+    L.SaveWeights(p, w2.encode())
+    assert open(w, "rb").read() == open(w2, "rb").read()
+    L.DkNetworkDestroy(p)
+    assert not L.LoadWeights(L.DkNetworkCreate(), b"/nonexistent.weights")
+    # fused: LoadNetwork(train=false) folds BN exactly like the oracle / reference
+    net = netutil.DkNet(dk, netutil.cfg_path(name), w)
+    onet = O.load_network(netutil.cfg_path(name), w)
+    L.DkLayerHostPtr.restype = C.POINTER(C.c_float)
+    L.DkLayerHostPtr.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    for i, l in enumerate(onet.layers):
+        if l.type != O.CONVOLUTIONAL:
+            continue
+        assert net.info(i)["batch_normalize"] == 0
+        wts = np.ctypeslib.as_array(L.DkLayerHostPtr(net.p, i, 1), shape=(l.nweights,))
+        bs = np.ctypeslib.as_array(L.DkLayerHostPtr(net.p, i, 2), shape=(l.n,))
+        assert np.array_equal(wts, l.weights) and np.array_equal(bs, l.biases), i
+    net.close()
+
+
+def test_nms_sort_vs_reference_golden(dk):
+    """NmsSort on the reference's own detection list (rebuilt by the oracle, which is
+    bit-identical) must reproduce the reference's post-NMS result."""
+    name = "yolov4-tiny"
+    g = np.load(os.path.join(GOLD, "net_%s.npz" % name))
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        w = os.path.join(d, "w.weights")
+        onet = O.parse_cfg(netutil.cfg_path(name))
+        synth.write_weights(w, [(l.n, l.c // l.groups, l.size, l.batch_normalize) for l in onet.layers if l.type == O.CONVOLUTIONAL])
+        onet = O.load_network(netutil.cfg_path(name), w)
+        O.forward(onet, synth.make_input(1, 3, 416, 416))
+    dets, _ = O.get_boxes(onet, float(g["thresh"]))
+    L = dk.lib()
+    L.DkNmsSortFlat.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float]
+    buf = np.ascontiguousarray(dets)
+    kind, beta = g["nms_kind_beta"]
+    L.DkNmsSortFlat(buf.ctypes.data, len(buf), buf.shape[1] - 5, float(g["nms_thresh"]), int(kind), float(beta))
+    assert np.array_equal(buf[:, :5], g["nms_box_obj"])
+    keep = buf[:, 5:] > 0
+    assert np.array_equal(keep.sum(1), g["nms_kept_per_det"])
+    assert np.array_equal(np.where(keep, buf[:, 5:], 0).sum(1, dtype=np.float64), g["nms_kept_prob_sum"])
+
+
+def test_compute_fails_loudly_without_gpu(dk):
+    if dk.have_gpu():
+        pytest.skip("a GPU is present")
+    code = ("import sys; sys.path.insert(0, %r); import numpy as np; import darknet_amd as dk; "
+            "from darknet_amd import netapi; n = netapi.DkNet(dk, netapi.cfg_path('yolov4-tiny')); "
+            "n.predict(np.zeros(n.inputs, np.float32))" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode != 0
+    assert b"no HIP device" in r.stderr or b"no CPU fallback" in r.stderr
+
+
+def test_synth_is_deterministic_and_matches_scalar_lcg():
+    g = synth.LCG(12345)
+    v = g.uniform(70000)
+    s = 12345
+    ref = []
+    for _ in range(70000):
+        s = (s * 1664525 + 1013904223) & 0xFFFFFFFF
+        ref.append((s >> 8) / 16777216.0)
+    assert np.array_equal(v, np.array(ref, np.float32))
+    assert np.array_equal(synth.make_input(2, 3, 8, 8), synth.make_input(2, 3, 8, 8))

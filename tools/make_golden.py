@@ -216,6 +216,17 @@ def gen_net(name, full_heads):
     out["det_best_class"] = np.argmax(dets[:, 5:], 1).astype(np.int32) if len(dets) else np.zeros(0, np.int32)
     out["det_best_prob"] = np.max(dets[:, 5:], 1) if len(dets) else np.zeros(0, np.float32)
     out["det_nonzero_classes"] = np.count_nonzero(dets[:, 5:], 1).astype(np.int32)
+    # NmsSort (src/box.cpp:393-419) on the reference's own detection list
+    nd = dets.copy()
+    classes = dets.shape[1] - 5
+    last = [l for l in onet.layers if l.type == O.YOLO][-1]
+    rn.L.ref_nms_sort(fp(nd), len(nd), classes, 0.45, last.nms_kind, last.beta_nms)
+    out["nms_thresh"] = np.float32(0.45)
+    out["nms_kind_beta"] = np.array([last.nms_kind, last.beta_nms], np.float32)
+    out["nms_box_obj"] = nd[:, :5].copy()
+    keep = nd[:, 5:] > 0
+    out["nms_kept_per_det"] = keep.sum(1).astype(np.int32)
+    out["nms_kept_prob_sum"] = np.where(keep, nd[:, 5:], 0).sum(1, dtype=np.float64)
     rn.close()
     np.savez_compressed(os.path.join(GOLD, f"net_{name}.npz"), **out)
     print(f"net_{name}.npz: layers {rn.n}, dets {len(dets)} at thresh {thresh:.6f}")
