@@ -82,6 +82,8 @@ def main():
     lo, hi = dkdist.shard_range(args.batch * ctx.world, ctx.rank, ctx.world)
     x = synth.make_input(hi, net.c, net.h, net.w)[lo:hi]
     L.DkSetPullHeads.argtypes = [C.c_int]
+    L.dk_conv_kernel_name.restype = C.c_char_p
+    L.dk_conv_kernel_name.argtypes = [C.c_int]
     L.cuda_push_array(L.DkNetworkInputGpu(net.p), x.ctypes.data, x.size)
     L.NetworkSync(net.p)
 
@@ -122,8 +124,8 @@ def main():
         prof_steps = 3
         for _ in range(prof_steps):
             step()
-        out = (C.c_double * (3 * 16))()
-        ncfg = L.dk_profile_read(out, 16)
+        out = (C.c_double * (3 * 64))()
+        ncfg = L.dk_profile_read(out, 64)
         L.dk_profile_enable(0)
         rows = [(out[3 * i + 2], out[3 * i], out[3 * i + 1], i) for i in range(ncfg) if out[3 * i] > 0]
         rows.sort(reverse=True)
@@ -134,7 +136,7 @@ def main():
         roofline = {
             "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-            "kernel": "conv_igemm_f32<%s>" % L.dk_conv_config_name(ci).decode(),
+            "kernel": L.dk_conv_kernel_name(ci).decode(),
             "launches_per_step": launches / prof_steps,
             "gflop_per_launch": gflop / launches, "avg_launch_ms": ms / launches,
             "all_conv_kernels": {"achieved": tot_gf / tot_ms, "frac": tot_gf / tot_ms / FP32_MFMA_PEAK_TFLOPS,

@@ -14,7 +14,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libdarknet_amd.so")
+LIB_PATH = os.environ.get("DK_LIB", os.path.join(HERE, "libdarknet_amd.so"))  # DK_LIB: dev A/B builds
 
 # ACTIVATION ids (reference src/yolo_core.h:69-92)
 LOGISTIC, RELU, LINEAR, LEAKY, MISH = 0, 1, 4, 8, 17

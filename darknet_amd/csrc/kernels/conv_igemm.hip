@@ -37,6 +37,7 @@
 #include <string.h>
 
 #include <map>
+#include <type_traits>
 #include <mutex>
 #include <vector>
 
@@ -55,9 +56,10 @@ struct ConvArgs
   float* y;
   const float* residual;
   float* act_in;
-  const int2* ktab;  // [Kpad] {element offset of tap k inside one image-group, tap bit index or -1}
+  const int2* ktab;  // [Kpad] {element offset of tap k inside one image-group, tap bit index (31 = padding)}
   unsigned x_bytes;  // buffer sizes for the hardware bounds check
   unsigned w_bytes;
+  unsigned y_bytes;
   int C, H, W;       // channels per group, input height/width
   int Ctot;          // total input channels
   int M, Mtot;       // filters per group / total
@@ -74,6 +76,14 @@ __device__ __forceinline__ float ld_buf(__amdgpu_buffer_rsrc_t r, unsigned byte_
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
 }
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_buf4(__amdgpu_buffer_rsrc_t r, unsigned byte_off)
+{
+  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
+      __uint_as_float(v.w));
+}
+
 // Bijective XCD remap (8 XCDs, blocks dealt round-robin): block `bid` of `nwg`
 // gets a logical id such that ids handled by one XCD are contiguous.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg)
@@ -84,7 +94,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
   return base + (bid >> 3);
 }
 
-template <int BM, int BN, int BK, int WM, int WN>
+constexpr unsigned OOB = 0x80000000u;  // ORed into a byte offset: always outside the buffer
+
+// AVEC: weights rows are read as float4 (needs K % 4 == 0).
+// BVEC: 1x1 / stride 1 / pad 0 / OHW % 4 == 0: the B tile is a plain strided
+//       matrix, read as float4 along n and written to LDS with ds_write_b128.
+template <int BM, int BN, int BK, int WM, int WN, bool AVEC, bool BVEC>
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
     conv_igemm_f32(const ConvArgs p)
 {
@@ -96,14 +111,24 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
   constexpr int A_FLOATS = BM * AS;
   constexpr int B_FLOATS = BK * BN;
   constexpr int STAGE = A_FLOATS + B_FLOATS;
-  constexpr int B_ROWS = T / BN;             // B rows gathered per pass
-  constexpr int PB = BK / B_ROWS;            // passes (elements per thread) for B
-  constexpr int A_ROWS = T / BK;             // A rows loaded per pass
-  constexpr int PA = BM / A_ROWS;
-  static_assert(T % BN == 0 && BN % 64 == 0, "B gather mapping");
-  static_assert(BK % B_ROWS == 0 && BM % A_ROWS == 0 && T % BK == 0, "tile mapping");
+  // generic B gather: thread = one pixel column, PB consecutive taps
+  constexpr int B_GROUPS = T / BN;           // wave-uniform row groups
+  constexpr int PB = BK / B_GROUPS;          // taps per thread
+  // vector B (1x1): thread = 4 pixels of one row
+  constexpr int NQ = BN / 4;
+  constexpr int BV_ROWS = T / NQ;
+  constexpr int PBV = BK / BV_ROWS;
+  // A: scalar (one k per thread) or float4 (4 k per thread)
+  constexpr int A_ROWS = T / BK;
+  constexpr int PA = (BM + A_ROWS - 1) / A_ROWS;
+  constexpr int KQ = BK / 4;
+  constexpr int AV_ROWS = T / KQ;
+  constexpr int PAV = (BM + AV_ROWS - 1) / AV_ROWS;
+  static_assert(T % BN == 0 && BN % 64 == 0 && BK % B_GROUPS == 0, "B gather mapping");
+  static_assert(T % BK == 0 && BK % BV_ROWS == 0 && BK % 8 == 0, "tile mapping");
+  static_assert((A_FLOATS % 4) == 0 && (STAGE % 4) == 0, "LDS alignment for ds_write_b128");
 
-  __shared__ float lds[2 * STAGE];
+  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -121,15 +146,30 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
   const int n0 = tile_n * BN;
 
   const int HW = p.H * p.W;
-  const float* wg = p.w + (size_t)g * p.M * p.K;
+  const int K = p.K;
+  const float* wg = p.w + (size_t)g * p.M * K;
   __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)wg, 0, p.w_bytes, 0x00020000);
 
-  // ---- per-thread B column: decompose n once ------------------------------
+  // ---- per-thread B addressing ----------------------------------------------
   const int bn_l = tid % BN;
-  const int bk_r = __builtin_amdgcn_readfirstlane(tid / BN);  // wave-uniform (BN % 64 == 0)
-  int xbase;      // element offset of (b, group g, iy0, ix0)
-  unsigned mask;  // bit t set <=> tap t is inside the image for this pixel
+  const int bk_g = __builtin_amdgcn_readfirstlane(tid / BN);  // wave-uniform (BN % 64 == 0)
+  unsigned xbase4 = 0;           // byte offset of (b, group g, iy0, ix0); may wrap "negative"
+  unsigned nmask = 0xFFFFFFFFu;  // bit t set <=> tap t is OUTSIDE the image (bit 31: table padding)
+  const int bq = tid % NQ;
+  const int bv_r = tid / NQ;
+  unsigned bv_base = OOB;        // BVEC: byte offset of (b, group g, channel 0, pix) or OOB
+  if (BVEC)
+  {
+    const int n = n0 + bq * 4;
+    if (n < p.N)
+    {
+      const int b = n / p.OHW;
+      const int pix = n - b * p.OHW;
+      bv_base = (unsigned)((b * p.Ctot + g * p.C) * HW + pix) * 4u;
+    }
+  }
+  else
   {
     const int n = n0 + bn_l;
     const bool nv = n < p.N;
@@ -140,48 +180,94 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
     const int ox = pix - oy * p.OW;
     const int iy0 = oy * p.stride_y - p.pad;
     const int ix0 = ox * p.stride_x - p.pad;
-    xbase = (b * p.Ctot + g * p.C) * HW + iy0 * p.W + ix0;
-    mask = 0;
+    xbase4 = (unsigned)((b * p.Ctot + g * p.C) * HW + iy0 * p.W + ix0) * 4u;
     if (nv)
     {
+      unsigned ok_bits = 0;
       for (int kh = 0; kh < p.size; ++kh)
         for (int kw = 0; kw < p.size; ++kw)
         {
           const bool ok = (unsigned)(iy0 + kh * p.dil) < (unsigned)p.H &&
                           (unsigned)(ix0 + kw * p.dil) < (unsigned)p.W;
-          mask |= (ok ? 1u : 0u) << (kh * p.size + kw);
+          ok_bits |= (ok ? 1u : 0u) << (kh * p.size + kw);
         }
+      nmask = ~ok_bits;
     }
   }
 
-  // ---- per-thread A element ------------------------------------------------
+  // ---- per-thread A addressing (loop invariant row offsets) -------------------
   const int ak_l = tid % BK;
   const int am_r = tid / BK;
+  const int aq = tid % KQ;
+  const int av_r = tid / KQ;
+  unsigned aoff[AVEC ? PAV : PA];
+  if (AVEC)
+  {
+#pragma unroll
+    for (int j = 0; j < PAV; ++j)
+    {
+      const int ml = av_r + j * AV_ROWS;
+      const int m = m0 + ml;
+      aoff[j] = (ml < BM && m < p.M) ? (unsigned)(m * K + aq * 4) * 4u : OOB;
+    }
+  }
+  else
+  {
+#pragma unroll
+    for (int j = 0; j < PA; ++j)
+    {
+      const int ml = am_r + j * A_ROWS;
+      const int m = m0 + ml;
+      aoff[j] = (ml < BM && m < p.M) ? (unsigned)(m * K + ak_l) * 4u : OOB;
+    }
+  }
 
-  float ra[PA], rb[PB];
+  float ra[AVEC ? PAV * 4 : PA];
+  float rb[BVEC ? PBV * 4 : PB];
 
   auto load_tile = [&](int k0) {
-    // B: one pixel column, PB taps (wave-uniform k per load)
-#pragma unroll
-    for (int j = 0; j < PB; ++j)
+    // ---- A (weights [M][K] row-major)
+    if (AVEC)
     {
-      const int k = k0 + bk_r + j * B_ROWS;
-      const int2 kt = p.ktab[k];  // scalar load: k is wave-uniform
-      const bool ok = (kt.y >= 0) && ((mask >> kt.y) & 1u);
-      const unsigned off = ok ? (unsigned)(xbase + kt.x) * 4u : 0xFFFFFFFCu;
-      rb[j] = ld_buf(xr, off);
-    }
-    // A: weights [M][K] row-major
-    {
-      const int k = k0 + ak_l;
-      const bool kv = k < p.K;
+      const unsigned kinv = (k0 + aq * 4 < K) ? 0u : OOB;
 #pragma unroll
-      for (int j = 0; j < PA; ++j)
+      for (int j = 0; j < PAV; ++j)
       {
-        const int m = m0 + am_r + j * A_ROWS;
-        const bool ok = kv && (m < p.M);
-        const unsigned off = ok ? (unsigned)(m * p.K + k) * 4u : 0xFFFFFFFCu;
-        ra[j] = ld_buf(wr, off);
+        const float4 v = ld_buf4(wr, (aoff[j] + (unsigned)k0 * 4u) | kinv);
+        ra[4 * j + 0] = v.x; ra[4 * j + 1] = v.y; ra[4 * j + 2] = v.z; ra[4 * j + 3] = v.w;
+      }
+    }
+    else
+    {
+      const unsigned kinv = (k0 + ak_l < K) ? 0u : OOB;
+#pragma unroll
+      for (int j = 0; j < PA; ++j) ra[j] = ld_buf(wr, (aoff[j] + (unsigned)k0 * 4u) | kinv);
+    }
+    // ---- B
+    if (BVEC)
+    {
+#pragma unroll
+      for (int j = 0; j < PBV; ++j)
+      {
+        const int k = k0 + bv_r + j * BV_ROWS;
+        const unsigned kinv = (k < K) ? 0u : OOB;
+        const float4 v = ld_buf4(xr, (bv_base + (unsigned)(k * HW) * 4u) | kinv);
+        rb[4 * j + 0] = v.x; rb[4 * j + 1] = v.y; rb[4 * j + 2] = v.z; rb[4 * j + 3] = v.w;
+      }
+    }
+    else
+    {
+      // PB consecutive table entries, wave-uniform address -> one wide scalar load
+      const int2* kp = p.ktab + (k0 + bk_g * PB);
+      int2 kt[PB];
+#pragma unroll
+      for (int j = 0; j < PB; ++j) kt[j] = kp[j];
+#pragma unroll
+      for (int j = 0; j < PB; ++j)
+      {
+        // kt.y = 31 - tap: shifts the tap's "outside" bit into the sign position
+        const unsigned inv = (nmask << kt[j].y) & OOB;
+        rb[j] = ld_buf(xr, (xbase4 + (unsigned)kt[j].x) | inv);
       }
     }
   };
@@ -189,10 +275,41 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
   auto store_tile = [&](float* st) {
     float* As = st;
     float* Bs = st + A_FLOATS;
+    if (AVEC)
+    {
 #pragma unroll
-    for (int j = 0; j < PA; ++j) As[(am_r + j * A_ROWS) * AS + ak_l] = ra[j];
+      for (int j = 0; j < PAV; ++j)
+      {
+        const int ml = av_r + j * AV_ROWS;
+        if (PAV * AV_ROWS == BM || ml < BM)
+        {
 #pragma unroll
-    for (int j = 0; j < PB; ++j) Bs[(bk_r + j * B_ROWS) * BN + bn_l] = rb[j];
+          for (int i = 0; i < 4; ++i) As[ml * AS + aq * 4 + i] = ra[4 * j + i];
+        }
+      }
+    }
+    else
+    {
+#pragma unroll
+      for (int j = 0; j < PA; ++j)
+      {
+        const int ml = am_r + j * A_ROWS;
+        if (PA * A_ROWS == BM || ml < BM)
+          As[ml * AS + ak_l] = ra[j];
+      }
+    }
+    if (BVEC)
+    {
+#pragma unroll
+      for (int j = 0; j < PBV; ++j)
+        *(float4*)&Bs[(bv_r + j * BV_ROWS) * BN + bq * 4] =
+            make_float4(rb[4 * j + 0], rb[4 * j + 1], rb[4 * j + 2], rb[4 * j + 3]);
+    }
+    else
+    {
+#pragma unroll
+      for (int j = 0; j < PB; ++j) Bs[(bk_g * PB + j) * BN + bn_l] = rb[j];
+    }
   };
 
   f32x16 acc[TM][TN];
@@ -203,7 +320,7 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nkt = (p.K + BK - 1) / BK;
+  const int nkt = (K + BK - 1) / BK;
   const int l31 = lane & 31, lh = lane >> 5;
 
   load_tile(0);
@@ -217,6 +334,9 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
     if (more)
       load_tile((kt + 1) * BK);
 
+    // MFMA step s contracts k = 2s (lanes 0-31) and 2s+1 (lanes 32-63): every
+    // output accumulates its K products in ascending k, like the reference's
+    // gemm_nn (src/gemm.c:2223-2239).
     const float* As = cur + (wm * WM + l31) * AS + lh;
     const float* Bs = cur + A_FLOATS + lh * BN + wn * WN + l31;
 #pragma unroll
@@ -240,16 +360,29 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
   }
 
   // ---- epilogue -----------------------------------------------------------
-  // C/D layout of 32x32x2: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // C/D layout of 32x32x2: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  // Output (and residual / pre-activation) addressed with 32-bit byte offsets
+  // through buffer descriptors (the host keeps one launch's output < 4 GiB).
+  __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.y_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, p.residual ? p.y_bytes : 0u, 0x00020000);
+  __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc((void*)p.act_in, 0, p.act_in ? p.y_bytes : 0u, 0x00020000);
+  const bool has_res = p.residual != nullptr, has_ain = p.act_in != nullptr;
+  const int act = p.act;
+  const bool full_tile = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+  unsigned obase[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j)
   {
     const int n = n0 + wn * WN + j * 32 + l31;
-    if (n >= p.N)
-      continue;
-    const int b = n / p.OHW;
-    const int pix = n - b * p.OHW;
-    const size_t obase = ((size_t)b * p.Mtot + (size_t)g * p.M) * p.OHW + pix;
+    const bool nv = n < p.N;
+    const int nn = nv ? n : 0;
+    const int b = nn / p.OHW;
+    const int pix = nn - b * p.OHW;
+    obase[j] = nv ? (unsigned)((b * p.Mtot + g * p.M) * p.OHW + pix) * 4u : 0xFFFFFFFFu;
+  }
+  const unsigned row_bytes = (unsigned)p.OHW * 4u;
+  auto emit = [&](auto check) {
+    constexpr bool CHECK = decltype(check)::value;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
     {
@@ -257,21 +390,31 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
       for (int r = 0; r < 16; ++r)
       {
         const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m >= p.M)
+        if (CHECK && m >= p.M)
           continue;
-        float v = acc[i][j][r];
-        if (p.bias)
-          v += p.bias[g * p.M + m];
-        const size_t o = obase + (size_t)m * p.OHW;
-        if (p.act_in)
-          p.act_in[o] = v;
-        v = dk_activate(v, p.act);
-        if (p.residual)
-          v += p.residual[o];
-        p.y[o] = v;
+        const float bv = p.bias ? p.bias[g * p.M + m] : 0.f;
+        const unsigned mo = (unsigned)m * row_bytes;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+        {
+          if (CHECK && obase[j] == 0xFFFFFFFFu)
+            continue;
+          float v = acc[i][j][r] + bv;
+          const unsigned o = obase[j] + mo;
+          if (has_ain)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ar, (int)o, 0, 0);
+          v = dk_activate(v, act);
+          if (has_res)
+            v += ld_buf(rr, o);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yr, (int)o, 0, 0);
+        }
       }
     }
-  }
+  };
+  if (full_tile)
+    emit(std::false_type{});
+  else
+    emit(std::true_type{});
 }
 
 // --------------------------------------------------------------------------
@@ -284,23 +427,28 @@ struct TileCfg
   int bm, bn, bk, wm, wn;
   float eff;  // relative MFMA efficiency used by the heuristic
   const char* name;
-  void (*kernel)(const ConvArgs);
+  void (*kernel[4])(const ConvArgs);  // [AVEC + 2*BVEC]
   int threads;
 };
 
-#define DK_CFG(BM, BN, BK, WM, WN, EFF)                                               \
-  {                                                                                   \
-    BM, BN, BK, WM, WN, EFF, #BM "x" #BN "x" #BK "_w" #WM "x" #WN,                    \
-        conv_igemm_f32<BM, BN, BK, WM, WN>, (BM / WM) * (BN / WN) * 64                \
+#define DK_CFG(BM, BN, BK, WM, WN, EFF)                                                     \
+  {                                                                                         \
+    BM, BN, BK, WM, WN, EFF, #BM "x" #BN "x" #BK "_w" #WM "x" #WN,                          \
+        {conv_igemm_f32<BM, BN, BK, WM, WN, false, false>,                                  \
+            conv_igemm_f32<BM, BN, BK, WM, WN, true, false>,                                \
+            conv_igemm_f32<BM, BN, BK, WM, WN, false, true>,                                \
+            conv_igemm_f32<BM, BN, BK, WM, WN, true, true>},                                \
+        (BM / WM) * (BN / WN) * 64                                                          \
   }
 
 const TileCfg g_cfgs[] = {
     DK_CFG(128, 128, 16, 64, 64, 1.00f),
-    DK_CFG(64, 128, 16, 32, 64, 0.92f),
-    DK_CFG(128, 64, 16, 64, 32, 0.92f),
-    DK_CFG(64, 64, 16, 32, 32, 0.80f),
-    DK_CFG(32, 128, 16, 32, 32, 0.72f),
-    DK_CFG(256, 128, 16, 64, 64, 1.04f),
+    DK_CFG(64, 128, 16, 32, 64, 0.95f),
+    DK_CFG(128, 64, 16, 64, 32, 0.97f),
+    DK_CFG(64, 64, 16, 32, 32, 0.92f),
+    DK_CFG(32, 128, 16, 32, 32, 0.80f),
+    DK_CFG(256, 128, 16, 64, 64, 0.98f),
+    DK_CFG(64, 256, 16, 32, 128, 0.95f),
 };
 const int g_ncfg = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
 
@@ -329,6 +477,17 @@ struct ProfRec
 };
 int g_prof_on = 0;
 std::vector<ProfRec> g_prof;
+
+bool fast_mish()
+{
+  static int v = -1;
+  if (v < 0)
+  {
+    const char* e = getenv("DK_FAST_MISH");  // default on; DK_FAST_MISH=0 = the reference's formula
+    v = (e && !atoi(e)) ? 0 : 1;
+  }
+  return v == 1;
+}
 
 int out_dim(int in, int pad, int size, int stride) { return (in + 2 * pad - size) / stride + 1; }
 
@@ -382,13 +541,13 @@ Plan& get_plan(const DkConvDesc* d, int K, int C)
       if (k < K)
       {
         const int c = k / ss, t = k % ss, kh = t / d->size, kw = t % d->size;
-        h[k].x = c * d->h * d->w + kh * d->dilation * d->w + kw * d->dilation;
-        h[k].y = t;
+        h[k].x = (c * d->h * d->w + kh * d->dilation * d->w + kw * d->dilation) * 4;  // bytes
+        h[k].y = 31 - t;  // left shift that brings tap t's bit to the sign position
       }
       else
       {
         h[k].x = 0;
-        h[k].y = -1;
+        h[k].y = 0;   // selects bit 31 of the "outside" mask, which is always set -> reads as 0
       }
     }
     CHECK_HIP(hipMalloc((void**)&pl.ktab, kpad * sizeof(int2)));
@@ -453,7 +612,19 @@ extern "C" int dk_profile_read(double* out, int max_cfgs)
     (void)hipEventDestroy(r.e1);
   }
   g_prof.clear();
-  return g_ncfg;
+  return g_ncfg * 4;
+}
+
+// Kernel symbol exactly as rocprofv3 prints it, for profile slot idx = cfg*4 + AVEC + 2*BVEC.
+extern "C" __attribute__((visibility("default"))) const char* dk_conv_kernel_name(int idx)
+{
+  static char buf[128];
+  if (idx < 0 || idx >= g_ncfg * 4)
+    return nullptr;
+  const TileCfg& c = g_cfgs[idx / 4];
+  snprintf(buf, sizeof(buf), "conv_igemm_f32<%d, %d, %d, %d, %d, %s, %s>", c.bm, c.bn, c.bk, c.wm,
+      c.wn, (idx & 1) ? "true" : "false", (idx & 2) ? "true" : "false");
+  return buf;
 }
 
 int dk_conv_num_configs() { return g_ncfg; }
@@ -480,9 +651,9 @@ int dk_conv_forward_cfg(const DkConvDesc* d, const float* x, const float* weight
     fprintf(stderr, "dk_conv_forward: invalid descriptor\n");
     return 1;
   }
-  if (d->size * d->size > 32)
+  if (d->size * d->size > 31)
   {
-    fprintf(stderr, "dk_conv_forward: kernel size %d unsupported (size*size must be <= 32)\n", d->size);
+    fprintf(stderr, "dk_conv_forward: kernel size %d unsupported (size*size must be <= 31)\n", d->size);
     return 1;
   }
   const int pad = d->pad * d->dilation;
@@ -508,13 +679,13 @@ int dk_conv_forward_cfg(const DkConvDesc* d, const float* x, const float* weight
   const size_t in_img = (size_t)d->c * d->h * d->w;
   const size_t out_img = (size_t)d->n * OH * OW;
   // the gather uses 32-bit byte offsets checked by the buffer descriptor:
-  // process the batch in chunks whose input stays below 4 GiB
-  const size_t max_elems = (size_t)1 << 30;
+  // process the batch in chunks whose input stays below 2 GiB
+  const size_t max_elems = (size_t)1 << 29;  // byte offsets stay below 2^31: bit 31 is the "masked" flag
   int chunk = d->batch;
-  if (in_img * (size_t)chunk >= max_elems || out_img * (size_t)chunk >= ((size_t)1 << 31))
+  if (in_img * (size_t)chunk >= max_elems || out_img * (size_t)chunk >= ((size_t)1 << 30))
   {
     chunk = (int)((max_elems - 1) / in_img);
-    const int c2 = (int)((((size_t)1 << 31) - 1) / out_img);
+    const int c2 = (int)((((size_t)1 << 30) - 1) / out_img);
     if (c2 < chunk)
       chunk = c2;
     if (chunk < 1)
@@ -539,6 +710,7 @@ int dk_conv_forward_cfg(const DkConvDesc* d, const float* x, const float* weight
     a.ktab = pl.ktab;
     a.x_bytes = (unsigned)(in_img * nb * sizeof(float));
     a.w_bytes = (unsigned)((size_t)M * K * sizeof(float));
+    a.y_bytes = (unsigned)(out_img * nb * sizeof(float));
     a.C = C; a.H = d->h; a.W = d->w; a.Ctot = d->c;
     a.M = M; a.Mtot = d->n; a.K = K;
     a.OH = OH; a.OW = OW; a.OHW = OH * OW;
@@ -546,6 +718,8 @@ int dk_conv_forward_cfg(const DkConvDesc* d, const float* x, const float* weight
     a.size = d->size; a.stride_x = d->stride_x; a.stride_y = d->stride_y;
     a.pad = pad; a.dil = d->dilation;
     a.act = d->activation;
+    if (d->activation == DK_MISH && fast_mish())
+      a.act |= DK_ACT_FAST;
     const int ci = (cfg_override >= 0 && cfg_override < g_ncfg) ? cfg_override : pick_cfg(M, a.N, d->groups);
     const TileCfg& c = g_cfgs[ci];
     a.tiles_m = (M + c.bm - 1) / c.bm;
@@ -564,12 +738,16 @@ int dk_conv_forward_cfg(const DkConvDesc* d, const float* x, const float* weight
       CHECK_HIP(hipEventCreate(&pr.e1));
       CHECK_HIP(hipEventRecord(pr.e0, st));
     }
-    hipLaunchKernelGGL(c.kernel, dim3((unsigned)nblk), dim3(c.threads), 0, st, a);
+    const bool avec = (K % 4 == 0) && (((uintptr_t)weights & 15) == 0);
+    const bool bvec = d->size == 1 && d->stride_x == 1 && d->stride_y == 1 && pad == 0 &&
+                      ((OH * OW) % 4 == 0) && (((uintptr_t)a.x & 15) == 0);
+    hipLaunchKernelGGL(c.kernel[(avec ? 1 : 0) + (bvec ? 2 : 0)], dim3((unsigned)nblk),
+        dim3(c.threads), 0, st, a);
     CHECK_HIP(hipPeekAtLastError());
     if (g_prof_on)
     {
       CHECK_HIP(hipEventRecord(pr.e1, st));
-      pr.cfg = ci;
+      pr.cfg = ci * 4 + (avec ? 1 : 0) + (bvec ? 2 : 0);
       pr.gflop = 2.0 * (double)M * K * d->groups * (double)a.N / 1e9;
       g_prof.push_back(pr);
     }

@@ -37,9 +37,26 @@ __device__ __forceinline__ float dk_mish(float x) { return x * dk_tanh(dk_softpl
 // literal (src/gemm.c:2642), narrowed on store.
 __device__ __forceinline__ float dk_leaky(float x) { return (x > 0.f) ? x : (float)(.1 * (double)x); }
 
+// Fast mish (conv epilogue default; DK_FAST_MISH=0 selects dk_mish; act bit 0x400): algebraically identical,
+// tanh(log(1+e)) = (e*e+2e)/(e*e+2e+2), one hardware exp and one division, no
+// cancellation.  Differs from the reference's own (cancellation-prone) formula
+// by at most ~|x|*1.2e-7 absolute, the same size as glibc-vs-device libm noise.
+__device__ __forceinline__ float dk_mish_fast(float x)
+{
+  if (x > 20.f)
+    return x;
+  const float e = __expf(x);
+  const float w = e * (e + 2.f);
+  return x * __fdividef(w, w + 2.f);
+}
+
+#define DK_ACT_FAST 0x400
+
 __device__ __forceinline__ float dk_activate(float x, int a)
 {
-  switch (a)
+  if (a == (DK_MISH | DK_ACT_FAST))
+    return dk_mish_fast(x);
+  switch (a & 0xff)
   {
     case DK_LINEAR: return x;
     case DK_LEAKY: return dk_leaky(x);

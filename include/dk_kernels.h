@@ -114,11 +114,15 @@ DK_API int dk_scal(size_t n, float alpha, float* x, void* stream);
 /* Profiling hooks used by bench.py (measurement only): when enabled every
  * dk_conv_forward is bracketed by HIP events on its stream; dk_profile_read
  * synchronises and returns per tile-configuration totals.
- *   out[cfg*3+0] = launches, out[cfg*3+1] = algorithmic GFLOP
+ * (slot = tile configuration * 4 + AVEC + 2*BVEC, i.e. one slot per kernel symbol):
+ *   out[slot*3+0] = launches, out[slot*3+1] = algorithmic GFLOP
  *   (2*nweights*oh*ow*batch/1e9, the reference's counter
- *   src/convolutional_layer.cpp:714), out[cfg*3+2] = milliseconds. */
+ *   src/convolutional_layer.cpp:714), out[slot*3+2] = milliseconds.
+ * Returns the number of slots; dk_conv_kernel_name(slot) is the kernel's name
+ * exactly as rocprofv3 prints it. */
 DK_API void dk_profile_enable(int on);
-DK_API int dk_profile_read(double* out, int max_cfgs);
+DK_API int dk_profile_read(double* out, int max_slots);
+DK_API const char* dk_conv_kernel_name(int slot);
 
 #ifdef __cplusplus
 }

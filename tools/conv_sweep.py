@@ -51,11 +51,11 @@ def main():
             L.dk_profile_enable(1)
             for _ in range(iters):
                 L.dk_conv_forward(C.byref(d), dx.ptr, wt.ptr, bs.ptr, dy.ptr, None, None, None)
-            out = (C.c_double * (3 * 16))()
-            L.dk_profile_read(out, 16)
+            out = (C.c_double * (3 * 64))()
+            L.dk_profile_read(out, 64)
             L.dk_profile_enable(0)
-            ms = out[cfgi * 3 + 2] / iters
-            gf = out[cfgi * 3 + 1] / iters
+            ms = sum(out[(cfgi * 4 + v) * 3 + 2] for v in range(4)) / iters
+            gf = sum(out[(cfgi * 4 + v) * 3 + 1] for v in range(4)) / iters
             times.append(ms)
         best = int(np.argmin(times))
         cnt = len(idxs)
