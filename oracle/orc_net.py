@@ -366,3 +366,129 @@ def get_boxes(net, thresh, b=0):
     if not dets:
         return np.zeros((0, 5), np.float32), np.zeros((0, 4), np.int32)
     return np.concatenate(dets), np.concatenate(ids)
+
+
+# ------------------------------------------------------------------ training
+def load_network_train(cfg, weights, batch):
+    """LoadNetwork(train=true) semantics for the layer kinds of the path: BN is
+    NOT folded; per-layer delta / update buffers are allocated and zeroed."""
+    net = parse_cfg(cfg, batch=batch, train=True)
+    if weights:
+        load_weights(net, weights)
+    for l in net.layers:
+        l.delta = np.zeros((l.batch, l.outputs), np.float32)
+        if l.type == CONVOLUTIONAL:
+            l.weight_updates = np.zeros(l.nweights, np.float32)
+            l.bias_updates = np.zeros(l.n, np.float32)
+            if l.batch_normalize:
+                l.scale_updates = np.zeros(l.n, np.float32)
+                for name in ("mean", "variance", "mean_delta", "variance_delta"):
+                    setattr(l, name, np.zeros(l.n, np.float32))
+    return net
+
+
+def forward_train(net, x):
+    """ForwardNetwork with state.train = 1 (src/network.cpp:101-114): every
+    l->delta is zeroed, conv = GEMM -> BN with batch statistics (rolling stats
+    updated) or bias -> activation (mish keeps its input).  The yolo layer only
+    decodes here; its delta (the loss gradient) is injected by the caller."""
+    L = lib()
+    x = np.ascontiguousarray(x, np.float32).reshape(net.batch, -1)
+    net.input = x
+    ws = np.zeros(net.workspace, np.float32)
+    inp = x
+    for l in net.layers:
+        B = l.batch
+        l.delta[...] = 0
+        out = np.zeros((B, l.outputs), np.float32)
+        if l.type == CONVOLUTIONAL:
+            L.orc_conv_gemm_forward(fptr(inp), fptr(l.weights), fptr(out), fptr(ws), B, l.c, l.h,
+                                    l.w, l.n, l.groups, l.size, l.stride_x, l.stride_y, l.dilation, l.pad)
+            sp = l.out_h * l.out_w
+            if l.batch_normalize:
+                l.x = np.zeros_like(out)
+                l.x_norm = np.zeros_like(out)
+                L.orc_batchnorm_forward(fptr(out), B, l.n, sp, fptr(l.scales), fptr(l.biases),
+                                        fptr(l.rolling_mean), fptr(l.rolling_variance), fptr(l.mean),
+                                        fptr(l.variance), fptr(l.x), fptr(l.x_norm), 1)
+            else:
+                L.orc_add_bias(fptr(out), fptr(l.biases), B, l.n, sp)
+            if l.activation == MISH:
+                l.activation_input = np.zeros_like(out)
+                L.orc_activate_array_mish(fptr(out), out.size, fptr(l.activation_input), fptr(out))
+            else:
+                L.orc_activate_array(fptr(out), out.size, l.activation)
+        elif l.type == MAXPOOL:
+            l.indexes = np.zeros((B, l.outputs), np.int32)
+            L.orc_maxpool_forward(fptr(inp), fptr(out), iptr(l.indexes), B, l.c, l.h, l.w, l.size,
+                                  l.stride_x, l.stride_y, l.pad)
+        elif l.type == ROUTE:
+            off = 0
+            for src, size in zip(l.input_layers, l.input_sizes):
+                L.orc_route_copy(fptr(net.layers[src].output), size, l.groups, l.group_id, B,
+                                 fptr(out), l.outputs, off)
+                off += size // l.groups
+        elif l.type == SHORTCUT:
+            L.orc_shortcut_forward(fptr(inp), fptr(net.layers[l.from_index].output), fptr(out), B * l.outputs)
+            L.orc_activate_array(fptr(out), B * l.outputs, l.activation)
+        elif l.type == UPSAMPLE:
+            L.orc_upsample_forward(fptr(inp), l.w, l.h, l.c, B, l.stride, F(l.scale), fptr(out))
+        elif l.type == YOLO:
+            L.orc_yolo_forward(fptr(inp), fptr(out), B, l.w, l.h, l.n, l.classes, F(l.scale_x_y))
+        l.output = out
+        inp = out
+    return inp
+
+
+def backward(net):
+    """BackwardNetwork (src/network.cpp:160-190) for the path's layer kinds."""
+    L = lib()
+    ws = np.zeros(net.workspace, np.float32)
+    for i in range(net.n - 1, -1, -1):
+        l = net.layers[i]
+        prev = net.layers[i - 1] if i > 0 else None
+        p_in = prev.output if prev is not None else net.input
+        p_delta = prev.delta if prev is not None else None
+        B = l.batch
+        tot = B * l.outputs
+        if l.type == YOLO:
+            p_delta += l.delta  # BackwardYoloLayer: axpy_cpu(1)
+        elif l.type == CONVOLUTIONAL:
+            if l.activation == MISH:
+                L.orc_gradient_array_mish(tot, fptr(l.activation_input), fptr(l.delta))
+            else:
+                L.orc_gradient_array(fptr(l.output), tot, l.activation, fptr(l.delta))
+            sp = l.out_h * l.out_w
+            if l.batch_normalize:
+                L.orc_batchnorm_backward(fptr(l.delta), B, l.n, sp, fptr(l.scales), fptr(l.x), fptr(l.x_norm),
+                                         fptr(l.mean), fptr(l.variance), fptr(l.mean_delta),
+                                         fptr(l.variance_delta), fptr(l.scale_updates))
+            else:
+                L.orc_backward_bias(fptr(l.bias_updates), fptr(l.delta), B, l.n, sp)
+            L.orc_conv_backward(fptr(p_in), fptr(l.weights), fptr(l.delta), fptr(l.weight_updates),
+                                fptr(p_delta) if p_delta is not None else None, fptr(ws), B, l.c, l.h, l.w,
+                                l.n, l.groups, l.size, l.stride_x, l.stride_y, l.dilation, l.pad)
+        elif l.type == ROUTE:
+            off = 0
+            for src, size in zip(l.input_layers, l.input_sizes):
+                L.orc_route_backward(fptr(l.delta), l.outputs, off, size, l.groups, l.group_id, B,
+                                     fptr(net.layers[src].delta))
+                off += size // l.groups
+        elif l.type == SHORTCUT:
+            L.orc_gradient_array(fptr(l.output), tot, l.activation, fptr(l.delta))
+            L.orc_shortcut_backward(fptr(l.delta), tot, fptr(p_delta), fptr(net.layers[l.from_index].delta))
+        elif l.type == MAXPOOL:
+            L.orc_maxpool_backward(fptr(l.delta), iptr(l.indexes), tot, fptr(p_delta))
+        elif l.type == UPSAMPLE:
+            L.orc_upsample_backward(fptr(l.delta), l.w, l.h, l.c, B, l.stride, F(l.scale), fptr(p_delta))
+
+
+def update(net, actual_batch, lr, momentum, decay):
+    """UpdateNetwork -> UpdateConvolutionalLayer (src/convolutional_layer.cpp:1382-1399)."""
+    L = lib()
+    for l in net.layers:
+        if l.type == CONVOLUTIONAL:
+            L.orc_conv_update(fptr(l.weights), fptr(l.weight_updates), l.nweights, fptr(l.biases),
+                              fptr(l.bias_updates), fptr(l.scales) if l.batch_normalize else None,
+                              fptr(l.scale_updates) if l.batch_normalize else None, l.n, actual_batch,
+                              F(lr), F(momentum), F(decay))

@@ -124,3 +124,46 @@ def test_whole_net_inference(name, tmp_path):
     assert np.array_equal(dets[:, :5], g["det_box_obj"])
     assert np.array_equal(np.argmax(dets[:, 5:], 1), g["det_best_class"])
     assert np.array_equal(np.max(dets[:, 5:], 1), g["det_best_prob"])
+
+
+def train_fixture(tmp_path, name="yolov4-tiny"):
+    g = np.load(os.path.join(GOLD, "train_%s.npz" % name))
+    B = int(g["batch"])
+    cfg = str(tmp_path / "t.cfg")
+    open(cfg, "w").write(open(os.path.join(ROOT, "cfg", name + ".cfg")).read().replace("batch=64", "batch=%d" % B))
+    net = O.parse_cfg(cfg)
+    wpath = str(tmp_path / "w.weights")
+    synth.write_weights(wpath, [(l.n, l.c // l.groups, l.size, l.batch_normalize) for l in net.layers if l.type == O.CONVOLUTIONAL], seed=2024)
+    x = synth.make_input(B, net.c, net.h, net.w, seed=12345)
+    return g, cfg, wpath, x
+
+
+def summ(a):
+    idx = np.linspace(0, a.size - 1, 16).astype(np.int64)
+    return np.concatenate([[np.sum(a, dtype=np.float64), np.sum(a.astype(np.float64) ** 2)], a[idx].astype(np.float64)])
+
+
+def inject_yolo_deltas(net, g):
+    for i, l in enumerate(net.layers):
+        if l.type == O.YOLO:
+            d = np.zeros(l.batch * l.outputs, np.float32)
+            d[g["yolo_%d_delta_idx" % i]] = g["yolo_%d_delta_val" % i]
+            l.delta[...] = d.reshape(l.delta.shape)
+
+
+def test_train_step_golden(tmp_path):
+    """One train step of the real reference (BN batch statistics, backward through
+    every layer kind, SGD update), driven by the reference's own yolo deltas."""
+    g, cfg, wpath, x = train_fixture(tmp_path)
+    net = O.load_network_train(cfg, wpath, None)
+    O.forward_train(net, x)
+    inject_yolo_deltas(net, g)
+    O.backward(net)
+    which_name = {7: "weight_updates", 8: "bias_updates", 9: "scale_updates", 6: "delta"}
+    for row in g["grad_summaries"]:
+        i, which = int(row[0]), int(row[1])
+        a = getattr(net.layers[i], which_name[which])
+        assert np.array_equal(summ(a.ravel()), row[2:]), (i, which_name[which])
+    O.update(net, net.batch * net.subdiv, float(g["lr"]), net.momentum, net.decay)
+    for row in g["updated_weight_summaries"]:
+        assert np.array_equal(summ(net.layers[int(row[0])].weights), row[1:])

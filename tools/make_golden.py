@@ -240,7 +240,79 @@ def main():
     gen_net("yolov4-tiny", full_heads=True)
     gen_net("yolov4", full_heads=False)
     gen_net("yolov4-csp", full_heads=False)
+    gen_train()
+
+
+def gen_train(name="yolov4-tiny", B=2):
+    """One train step of the real reference (forward with batch-norm statistics,
+    yolo loss, backward, SGD update) -> train_<cfg>.npz.  The yolo-layer deltas
+    (the loss gradient, host C++ in the reference too) are stored sparsely so that
+    the oracle's / the HIP path's backward can be driven from them."""
+    cfg_txt = open(os.path.join(ROOT, "cfg", name + ".cfg")).read().replace("batch=64", "batch=%d" % B)
+    cfg = f"/tmp/_dk_{name}_b{B}.cfg"
+    open(cfg, "w").write(cfg_txt)
+    net = O.parse_cfg(cfg)
+    convs = [(l.n, l.c // l.groups, l.size, l.batch_normalize) for l in net.layers if l.type == O.CONVOLUTIONAL]
+    wpath = f"/tmp/_dk_{name}.weights"
+    synth.write_weights(wpath, convs, seed=2024)
+    x = synth.make_input(B, net.c, net.h, net.w, seed=12345)
+    truth = np.zeros((B, 90 * 5), np.float32)
+    for b in range(B):
+        for t, box in enumerate([(.3, .4, .2, .3, 1), (.6, .5, .4, .35, 17), (.8, .2, .1, .15, 60)]):
+            truth[b, t * 5:(t + 1) * 5] = box
+    rn = reflib.RefNet(cfg, wpath, train=True)
+    rn.L.ref_set_max_iter(rn.p, 1000)
+    cost = rn.L.ref_train_datum(rn.p, fp(x), fp(truth))
+    out = {"batch": np.int32(B), "truth": truth, "cost": np.float32(cost)}
+    onet = O.load_network_train(cfg, wpath, None)
+    O.forward_train(onet, x)
+    for i, l in enumerate(onet.layers):
+        assert np.array_equal(rn.output(i), l.output.ravel()), f"train forward: oracle != reference at {i}"
+        if l.type == O.YOLO:
+            d = rn.arr(i, 6, l.batch * l.outputs)
+            nz = np.flatnonzero(d)
+            out[f"yolo_{i}_delta_idx"] = nz.astype(np.int64)
+            out[f"yolo_{i}_delta_val"] = d[nz]
+            l.delta[...] = d.reshape(l.delta.shape)
+    O.backward(onet)
+
+    def summ(a):
+        idx = np.linspace(0, a.size - 1, 16).astype(np.int64)
+        return np.concatenate([[np.sum(a, dtype=np.float64), np.sum(a.astype(np.float64) ** 2)], a[idx].astype(np.float64)])
+    rows = []
+    for i, l in enumerate(onet.layers):
+        if l.type != O.CONVOLUTIONAL:
+            continue
+        for which, nm, n in ((7, "weight_updates", l.nweights), (8, "bias_updates", l.n), (9, "scale_updates", l.n)):
+            r = rn.arr(i, which, n)
+            o = getattr(l, nm, None)
+            if r is None or o is None:
+                continue
+            assert np.array_equal(r, o), f"train backward: oracle != reference at {i} {nm}"
+            rows.append(np.concatenate([[i, which], summ(r)]))
+        rows.append(np.concatenate([[i, 6], summ(rn.arr(i, 6, l.batch * l.outputs))]))
+    out["grad_summaries"] = np.array(rows)
+    # SGD update (UpdateNetwork: lr from GetCurrLr at iteration 1 of burn-in)
+    rn.L.ref_update(rn.p)
+    lr = float(rn.L.ref_curr_lr(rn.p))
+    out["lr"] = np.float32(lr)
+    O.update(onet, onet.batch * onet.subdiv, lr, onet.momentum, onet.decay)
+    rows = []
+    for i, l in enumerate(onet.layers):
+        if l.type != O.CONVOLUTIONAL:
+            continue
+        r = rn.arr(i, 1, l.nweights)
+        assert np.array_equal(r, l.weights), f"update: oracle != reference at {i}"
+        assert np.array_equal(rn.arr(i, 2, l.n), l.biases)
+        rows.append(np.concatenate([[i], summ(r)]))
+    out["updated_weight_summaries"] = np.array(rows)
+    rn.close()
+    np.savez_compressed(os.path.join(GOLD, f"train_{name}.npz"), **out)
+    print(f"train_{name}.npz: cost {cost:.4f}, lr {lr:.3e}")
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "train":
+        gen_train()
+    else:
+        main()
