@@ -105,6 +105,8 @@ void FillConvLayer(layer* l, int batch, int h, int w, int c, int n, int groups, 
   l->forward = no_cpu_path;
   l->backward = no_cpu_path;
   l->forward_gpu = ForwardConvolutionalLayerGpu;
+  l->backward_gpu = BackwardConvolutionalLayerGpu;
+  l->update_gpu = UpdateConvolutionalLayerGpu;
 
   if (batch_normalize)
   {
@@ -181,7 +183,8 @@ void DkConvPrepare(layer* l)
 
 // Inference (BN folded or no BN): one fused launch.  Train mode with BN is
 // handled in train.cpp (raw GEMM, then batch statistics, then activation).
-void ForwardConvTrainGpu(layer* l, NetworkState state);  // train.cpp (weak until built)
+void ForwardConvTrainGpu(layer* l, NetworkState state);  // train.cpp
+void DkYoloTrainDelta(layer* l, NetworkState state);      // train.cpp
 
 void ForwardConvolutionalLayerGpu(layer* l, NetworkState state)
 {
@@ -275,6 +278,7 @@ void FillMaxpoolLayer(layer* l, int batch, int h, int w, int c, int size, int st
   l->forward = no_cpu_path;
   l->backward = no_cpu_path;
   l->forward_gpu = ForwardMaxpoolLayerGpu;
+  l->backward_gpu = BackwardMaxpoolLayerGpu;
   if (dk_gpu_enabled())
   {
     if (train)
@@ -317,8 +321,13 @@ void FillRouteLayer(layer* l, int batch, int n, int* input_layers, int* input_si
   l->forward = no_cpu_path;
   l->backward = no_cpu_path;
   l->forward_gpu = ForwardRouteLayerGpu;
+  l->backward_gpu = BackwardRouteLayerGpu;
   if (dk_gpu_enabled())
+  {
     l->output_gpu = cuda_make_array(nullptr, (size_t)outputs * batch);
+    l->delta_gpu = cuda_make_array(nullptr, (size_t)outputs * batch);
+    CHECK_HIP(hipMemsetAsync(l->delta_gpu, 0, (size_t)outputs * batch * sizeof(float), get_cuda_stream()));
+  }
 }
 
 void ForwardRouteLayerGpu(layer* l, NetworkState state)
@@ -360,6 +369,7 @@ void FillShortcutLayer(layer* l, int batch, int index, int w, int h, int c, int 
   l->forward = no_cpu_path;
   l->backward = no_cpu_path;
   l->forward_gpu = ForwardShortcutLayerGpu;
+  l->backward_gpu = BackwardShortcutLayerGpu;
   if (dk_gpu_enabled())
   {
     l->output_gpu = cuda_make_array(nullptr, (size_t)l->outputs * batch);
@@ -408,8 +418,13 @@ void FillUpsampleLayer(layer* l, int batch, int w, int h, int c, int stride)
   l->forward = no_cpu_path;
   l->backward = no_cpu_path;
   l->forward_gpu = ForwardUpsampleLayerGpu;
+  l->backward_gpu = BackwardUpsampleLayerGpu;
   if (dk_gpu_enabled())
+  {
     l->output_gpu = cuda_make_array(nullptr, (size_t)l->outputs * batch);
+    l->delta_gpu = cuda_make_array(nullptr, (size_t)l->outputs * batch);
+    CHECK_HIP(hipMemsetAsync(l->delta_gpu, 0, (size_t)l->outputs * batch * sizeof(float), get_cuda_stream()));
+  }
 }
 
 void ForwardUpsampleLayerGpu(layer* l, NetworkState state)
@@ -450,10 +465,13 @@ void FillYoloLayer(layer* l, int batch, int w, int h, int n, int total, int* mas
   l->forward = no_cpu_path;
   l->backward = no_cpu_path;
   l->forward_gpu = ForwardYoloLayerGpu;
+  l->backward_gpu = BackwardYoloLayerGpu;
   const size_t total_out = (size_t)batch * l->outputs;
   if (dk_gpu_enabled())
   {
     l->output_gpu = cuda_make_array(nullptr, total_out);
+    l->delta_gpu = cuda_make_array(nullptr, total_out);
+    CHECK_HIP(hipMemsetAsync(l->delta_gpu, 0, total_out * sizeof(float), get_cuda_stream()));
     // pinned host mirror, as the reference does (yolo_layer.cpp:63-72)
     l->output = cuda_make_array_pinned(nullptr, total_out);
     l->output_pinned = 1;
@@ -470,6 +488,8 @@ void ForwardYoloLayerGpu(layer* l, NetworkState state)
     error("ForwardYoloLayerGpu failed");
   // D2H of the decoded head is issued by the graph engine (network.cpp) so that
   // it can run on the copy stream / outside a captured graph.
+  if (state.train && !l->onlyforward)
+    DkYoloTrainDelta(l, state);
 }
 
 // EntryIndex, yolo_layer.cpp:380-386

@@ -523,6 +523,7 @@ void FreeNetwork(Network* net)
     if (net->input_pinned_cpu_flag)
       cuda_free_host(net->input_pinned_cpu);
     cuda_free(net->workspace);
+    cuda_free(net->wt_scratch_gpu);
   }
   memset(net, 0, sizeof(*net));
 }

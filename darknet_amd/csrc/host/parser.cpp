@@ -403,6 +403,14 @@ static bool parse_cfg_batch(Network* net, char const* filename, bool train, int 
     net->input_pinned_cpu_flag = 1;
     if (workspace_size)
       net->workspace = cuda_make_array(0, workspace_size / sizeof(float) + 1);
+    if (train)
+    {
+      size_t maxw = 1;
+      for (int i = 0; i < net->n; ++i)
+        if (net->layers[i].type == CONVOLUTIONAL && (size_t)net->layers[i].nweights > maxw)
+          maxw = net->layers[i].nweights;
+      net->wt_scratch_gpu = cuda_make_array(0, maxw);
+    }
     CHECK_HIP(hipStreamSynchronize(get_cuda_stream()));
   }
   // host mirror of the last layer for NetworkPredict's return value

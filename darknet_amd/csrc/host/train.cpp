@@ -1,19 +1,297 @@
-// train.cpp -- training-mode layer paths (BN with batch statistics, backward,
-// update).  Round-1 status: the inference path (BN folded) is complete; the
-// train-mode conv forward below is the un-fused sequence conv GEMM -> BN
-// (rolling statistics when state.train == 0) -> activation.
+// train.cpp -- training-mode graph engine: conv forward with batch statistics,
+// the backward sweep, the SGD update.  Reference twins (Ravicmoon/darknet src/):
+// ForwardConvolutionalLayerGpu + ForwardBatchnormLayerGpu convolutional_kernels.cu
+// :471-532 / batchnorm_layer.cpp:268-322; BackwardConvolutionalLayerGpu :555-815;
+// UpdateConvolutionalLayerGpu :865-921; BackwardNetworkGpu / UpdateNetworkGpu /
+// ForwardBackwardNetworkGpu / TrainNetworkDatumGpu network_kernels.cu:116-293;
+// Backward{Maxpool,Route,Shortcut,Upsample,Yolo}LayerGpu.
+// Numerics follow the reference's CPU path:
+// BN eps / rolling momentum / N-1 variance as on the CPU; the data gradient
+// OVERWRITES the previous layer's delta; for BN layers bias_updates is the true
+// sum of delta (the CPU reference leaves it 0 -- quirk 3).
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "dk_host.h"
 #include "dk_internal.h"
 
+extern "C" {
+int dk_bn_forward_train(const float*, float*, float*, float*, float*, float*, float*, float*, float*,
+    const float*, const float*, int, int, int, int, int, void*);
+}
+
+static DkConvDesc conv_desc_of(const layer* l, int activation)
+{
+  DkConvDesc d;
+  d.batch = l->batch; d.c = l->c; d.h = l->h; d.w = l->w; d.n = l->n; d.groups = l->groups;
+  d.size = l->size; d.stride_x = l->stride_x; d.stride_y = l->stride_y;
+  d.dilation = l->dilation; d.pad = l->pad; d.activation = activation;
+  return d;
+}
+
+// conv with un-folded batch norm: raw GEMM -> x_gpu, statistics, normalise+scale+bias+act
 void ForwardConvTrainGpu(layer* l, NetworkState state)
 {
+  hipStream_t st = get_cuda_stream();
+  const int spatial = l->out_h * l->out_w;
+  const size_t total = (size_t)l->batch * l->outputs;
+  float* raw = l->x_gpu;
+  bool temp = false;
+  if (!raw)
+  {
+    // inference on a train-mode parse without train buffers: borrow the output buffer
+    raw = l->output_gpu;
+    temp = true;
+  }
+  DkConvDesc d = conv_desc_of(l, (int)LINEAR);
+  if (dk_conv_forward_cfg(&d, state.input, l->weights_gpu, nullptr, raw, nullptr, nullptr, st, -1))
+    error("ForwardConvolutionalLayerGpu (train) failed");
+  float* act_in = (state.train && l->activation_input_gpu) ? l->activation_input_gpu : nullptr;
+  const int train = state.train && !temp;
+  if (dk_bn_forward_train(raw, raw, l->x_norm_gpu, act_in, l->output_gpu, l->mean_gpu,
+          l->variance_gpu, l->rolling_mean_gpu, l->rolling_variance_gpu, l->scales_gpu,
+          l->biases_gpu, l->batch, l->n, spatial, (int)l->activation, train, st))
+    error("batch-norm forward failed");
+  (void)total;
+}
+
+void BackwardConvolutionalLayerGpu(layer* l, NetworkState state)
+{
+  hipStream_t st = get_cuda_stream();
+  const int spatial = l->out_h * l->out_w;
+  const size_t total = (size_t)l->batch * l->outputs;
+  if (dk_gradient_array(l->output_gpu, l->activation_input_gpu, l->delta_gpu, total,
+          (int)l->activation, st))
+    error("activation gradient failed");
+  if (l->batch_normalize)
+  {
+    if (dk_bn_backward(l->delta_gpu, l->x_gpu, l->x_norm_gpu, l->mean_gpu, l->variance_gpu,
+            l->scales_gpu, l->mean_delta_gpu, l->variance_delta_gpu, l->scale_updates_gpu,
+            l->bias_updates_gpu, l->batch, l->n, spatial, st))
+      error("batch-norm backward failed");
+  }
+  else
+    dk_backward_bias(l->bias_updates_gpu, l->delta_gpu, l->batch, l->n, spatial, st);
+
+  DkConvDesc d = conv_desc_of(l, (int)LINEAR);
+  if (dk_conv_backward_weights(&d, state.input, l->delta_gpu, l->weight_updates_gpu, st))
+    error("weight gradient failed");
+  if (state.delta)
+  {
+    const int Cg = l->c / l->groups, Mg = l->n / l->groups;
+    float* wt = state.net->wt_scratch_gpu;
+    for (int g = 0; g < l->groups; ++g)
+      dk_transpose_weights(l->weights_gpu + (size_t)g * l->nweights / l->groups,
+          wt + (size_t)g * l->nweights / l->groups, Mg, Cg, l->size, st);
+    if (dk_conv_backward_data(&d, l->delta_gpu, wt, state.delta, st))
+      error("data gradient failed");
+  }
+}
+
+void UpdateConvolutionalLayerGpu(layer* l, int batch, float learning_rate_init, float momentum,
+    float decay, float loss_scale)
+{
+  hipStream_t st = get_cuda_stream();
+  const float lr = learning_rate_init * l->learning_rate_scale;
+  if (loss_scale != 1.0f)
+  {
+    dk_scal(l->nweights, 1.0f / loss_scale, l->weight_updates_gpu, st);
+    dk_scal(l->n, 1.0f / loss_scale, l->bias_updates_gpu, st);
+    if (l->scale_updates_gpu)
+      dk_scal(l->n, 1.0f / loss_scale, l->scale_updates_gpu, st);
+  }
+  dk_sgd_update(l->weights_gpu, l->weight_updates_gpu, l->nweights, batch, lr, momentum, decay, 1, st);
+  dk_sgd_update(l->biases_gpu, l->bias_updates_gpu, l->n, batch, lr, momentum, decay, 0, st);
+  if (l->scales_gpu)
+    dk_sgd_update(l->scales_gpu, l->scale_updates_gpu, l->n, batch, lr, momentum, decay, 0, st);
+}
+
+void BackwardMaxpoolLayerGpu(layer* l, NetworkState state)
+{
+  if (!state.delta)
+    return;
+  dk_maxpool_backward(l->delta_gpu, l->indexes_gpu, (size_t)l->batch * l->outputs, state.delta,
+      get_cuda_stream());
+}
+
+void BackwardRouteLayerGpu(layer* l, NetworkState state)
+{
+  int offset = 0;
+  for (int i = 0; i < l->n; ++i)
+  {
+    layer* src = &state.net->layers[l->input_layers[i]];
+    const int input_size = l->input_sizes[i];
+    if (src->delta_gpu)
+      dk_route_backward(l->delta_gpu, l->outputs, offset, input_size, l->groups, l->group_id,
+          l->batch, src->delta_gpu, get_cuda_stream());
+    offset += input_size / l->groups;
+  }
+}
+
+void BackwardShortcutLayerGpu(layer* l, NetworkState state)
+{
+  hipStream_t st = get_cuda_stream();
+  const size_t total = (size_t)l->batch * l->outputs;
+  dk_gradient_array(l->output_gpu, nullptr, l->delta_gpu, total, (int)l->activation, st);
+  layer* from = &state.net->layers[l->index];
+  dk_shortcut_backward(l->delta_gpu, total, state.delta, from->delta_gpu, st);
+}
+
+void BackwardUpsampleLayerGpu(layer* l, NetworkState state)
+{
+  if (!state.delta)
+    return;
+  dk_upsample_backward(l->delta_gpu, l->w, l->h, l->c, l->batch, l->stride, l->scale, state.delta,
+      get_cuda_stream());
+}
+
+void BackwardYoloLayerGpu(layer* l, NetworkState state)
+{
+  // axpy_ongpu(batch*inputs, loss_scale, delta_gpu, state.delta), yolo_layer.cpp:884-888
+  dk_axpy((size_t)l->batch * l->inputs, state.net->loss_scale, l->delta_gpu, state.delta,
+      get_cuda_stream());
+}
+
+void DkSetYoloDelta(Network* net, int i, float* host_delta)
+{
+  if (i < 0 || i >= net->n || net->layers[i].type != YOLO)
+    error("DkSetYoloDelta: not a yolo layer");
+  net->layers[i].injected_delta = host_delta;
+}
+
+void DkSetMaxIter(Network* net, int max_iter) { net->max_iter = max_iter; }
+
+// called by ForwardYoloLayerGpu in train mode (layers.cpp)
+void DkYoloTrainDelta(layer* l, NetworkState state)
+{
   (void)state;
-  fprintf(stderr,
-      "darknet_amd: layer %d: convolution with un-folded batch_normalize (train-mode load) is not "
-      "implemented in this build; load with LoadNetwork(train=false) / LoadNetworkBatch.\n",
-      l->index);
-  exit(EXIT_FAILURE);
+  if (!l->injected_delta)
+  {
+    fprintf(stderr,
+        "darknet_amd: yolo layer %d: the detection loss (reference src/yolo_layer.cpp:413-772, host "
+        "C++) is not part of this build yet; drive the backward pass with DkSetYoloDelta().\n",
+        l->index);
+    exit(EXIT_FAILURE);
+  }
+  cuda_push_array(l->delta_gpu, l->injected_delta, (size_t)l->batch * l->outputs);
+}
+
+void BackwardNetworkGpu(Network* net, NetworkState state)
+{
+  state.workspace = net->workspace;
+  float* original_input = state.input;
+  float* original_delta = state.delta;
+  for (int i = net->n - 1; i >= 0; --i)
+  {
+    state.index = i;
+    layer* l = &net->layers[i];
+    if (l->stopbackward == 1)
+      break;
+    if (l->stopbackward > net->curr_iter)
+      break;
+    if (i == 0)
+    {
+      state.input = original_input;
+      state.delta = original_delta;
+    }
+    else
+    {
+      layer* prev = &net->layers[i - 1];
+      state.input = prev->output_gpu;
+      state.delta = prev->delta_gpu;
+    }
+    if (l->onlyforward)
+      continue;
+    if (l->backward_gpu)
+      l->backward_gpu(l, state);
+  }
+}
+
+void UpdateNetworkGpu(Network* net)
+{
+  cuda_set_device(net->gpu_index);
+  const int actual_batch = net->batch * net->subdiv;
+  const int iter = net->curr_iter;
+  const float lr = GetCurrLr(net);
+  for (int i = 0; i < net->n; ++i)
+  {
+    layer* l = &net->layers[i];
+    if (l->burnin_update && (l->burnin_update * net->burn_in > iter))
+      continue;
+    if (l->train_only_bn)
+      continue;
+    if (l->update_gpu && l->dont_update < iter)
+      l->update_gpu(l, actual_batch, lr, net->momentum, net->decay, net->loss_scale);
+  }
+}
+
+void UpdateNetwork(Network* net) { UpdateNetworkGpu(net); }
+
+void ForwardBackwardNetworkGpu(Network* net, float* x, float* y)
+{
+  (void)y;  // truth is consumed by the (host) yolo loss only
+  if (net->gpu_index < 0)
+    error("TrainNetworkDatum: no HIP device (this library has no CPU fallback)");
+  if (!net->train)
+    error("TrainNetworkDatum: the network was loaded for inference (LoadNetwork(train = true))");
+  NetworkState state;
+  memset(&state, 0, sizeof(state));
+  state.net = net;
+  const size_t x_size = (size_t)GetNetworkInputSize(net) * net->batch;
+  memcpy(net->input_pinned_cpu, x, x_size * sizeof(float));
+  cuda_push_array(net->input_state_gpu, net->input_pinned_cpu, x_size);
+  state.input = net->input_state_gpu;
+  state.delta = 0;
+  state.truth = 0;
+  state.train = 1;
+  ForwardNetworkGpu(net, state);
+  BackwardNetworkGpu(net, state);
+}
+
+float TrainNetworkDatumGpu(Network* net, float* x, float* y)
+{
+  net->seen += net->batch;
+  ForwardBackwardNetworkGpu(net, x, y);
+  CHECK_HIP(hipStreamSynchronize(get_cuda_stream()));
+  // GetNetworkCost (network.cpp:145-158): mean of the layers' cost[0]
+  float sum = 0;
+  int count = 0;
+  for (int i = 0; i < net->n; ++i)
+    if (net->layers[i].cost)
+    {
+      sum += net->layers[i].cost[0];
+      ++count;
+    }
+  return count ? sum / count : 0;
+}
+
+float TrainNetworkDatum(Network* net, float* x, float* y) { return TrainNetworkDatumGpu(net, x, y); }
+
+long DkLayerPull(Network* net, int i, int which, float* dst, size_t n)
+{
+  if (i < 0 || i >= net->n || net->gpu_index < 0)
+    return -1;
+  layer* l = &net->layers[i];
+  float* p = nullptr;
+  size_t cnt = 0;
+  switch (which)
+  {
+    case 1: p = l->weights_gpu; cnt = l->nweights; break;
+    case 2: p = l->biases_gpu; cnt = l->n; break;
+    case 3: p = l->scales_gpu; cnt = l->n; break;
+    case 4: p = l->rolling_mean_gpu; cnt = l->n; break;
+    case 5: p = l->rolling_variance_gpu; cnt = l->n; break;
+    case 6: p = l->delta_gpu; cnt = (size_t)l->batch * l->outputs; break;
+    case 7: p = l->weight_updates_gpu; cnt = l->nweights; break;
+    case 8: p = l->bias_updates_gpu; cnt = l->n; break;
+    case 9: p = l->scale_updates_gpu; cnt = l->n; break;
+    case 10: p = l->mean_gpu; cnt = l->n; break;
+    case 11: p = l->variance_gpu; cnt = l->n; break;
+  }
+  if (!p || n < cnt)
+    return -1;
+  NetworkSync(net);
+  cuda_pull_array(p, dst, cnt);
+  return (long)cnt;
 }

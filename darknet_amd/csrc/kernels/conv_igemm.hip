@@ -69,6 +69,7 @@ struct ConvArgs
   int size, stride_x, stride_y, pad, dil;  // pad = l->pad*dilation
   int act;
   int tiles_m, tiles_n, groups;
+  int mode;          // 0 forward gather; 1 data-gradient gather (x = delta, H/W = delta dims, OH/OW = input dims)
 };
 
 __device__ __forceinline__ float ld_buf(__amdgpu_buffer_rsrc_t r, unsigned byte_off)
@@ -178,20 +179,48 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
     const int pix = nn - b * p.OHW;
     const int oy = pix / p.OW;
     const int ox = pix - oy * p.OW;
-    const int iy0 = oy * p.stride_y - p.pad;
-    const int ix0 = ox * p.stride_x - p.pad;
-    xbase4 = (unsigned)((b * p.Ctot + g * p.C) * HW + iy0 * p.W + ix0) * 4u;
-    if (nv)
+    if (p.mode == 0)
     {
-      unsigned ok_bits = 0;
-      for (int kh = 0; kh < p.size; ++kh)
-        for (int kw = 0; kw < p.size; ++kw)
-        {
-          const bool ok = (unsigned)(iy0 + kh * p.dil) < (unsigned)p.H &&
-                          (unsigned)(ix0 + kw * p.dil) < (unsigned)p.W;
-          ok_bits |= (ok ? 1u : 0u) << (kh * p.size + kw);
-        }
-      nmask = ~ok_bits;
+      const int iy0 = oy * p.stride_y - p.pad;
+      const int ix0 = ox * p.stride_x - p.pad;
+      xbase4 = (unsigned)((b * p.Ctot + g * p.C) * HW + iy0 * p.W + ix0) * 4u;
+      if (nv)
+      {
+        unsigned ok_bits = 0;
+        for (int kh = 0; kh < p.size; ++kh)
+          for (int kw = 0; kw < p.size; ++kw)
+          {
+            const bool ok = (unsigned)(iy0 + kh * p.dil) < (unsigned)p.H &&
+                            (unsigned)(ix0 + kw * p.dil) < (unsigned)p.W;
+            ok_bits |= (ok ? 1u : 0u) << (kh * p.size + kw);
+          }
+        nmask = ~ok_bits;
+      }
+    }
+    else
+    {
+      // data gradient: this thread's pixel is an INPUT pixel (iy, ix) = (oy, ox) here;
+      // tap (kh, kw) contributes delta[(iy + pad - kh*dil)/stride] when divisible and
+      // in range.  With q = iy + pad = s*a + r and kh*dil = s*u + v: valid iff v == r,
+      // and then the delta row is a - u -> offset = base(a) + table(tap).
+      const int qy = oy + p.pad, qx = ox + p.pad;
+      const int ay = qy / p.stride_y, ry = qy - ay * p.stride_y;
+      const int ax = qx / p.stride_x, rx = qx - ax * p.stride_x;
+      xbase4 = (unsigned)((b * p.Ctot + g * p.C) * HW + ay * p.W + ax) * 4u;
+      if (nv)
+      {
+        unsigned ok_bits = 0;
+        for (int kh = 0; kh < p.size; ++kh)
+          for (int kw = 0; kw < p.size; ++kw)
+          {
+            const int uy = (kh * p.dil) / p.stride_y, vy = kh * p.dil - uy * p.stride_y;
+            const int ux = (kw * p.dil) / p.stride_x, vx = kw * p.dil - ux * p.stride_x;
+            const bool ok = vy == ry && vx == rx && (unsigned)(ay - uy) < (unsigned)p.H &&
+                            (unsigned)(ax - ux) < (unsigned)p.W;
+            ok_bits |= (ok ? 1u : 0u) << (kh * p.size + kw);
+          }
+        nmask = ~ok_bits;
+      }
     }
   }
 
@@ -522,12 +551,16 @@ int pick_cfg(int M, long long N, int groups)
   return best;
 }
 
-Plan& get_plan(const DkConvDesc* d, int K, int C)
+Plan& get_plan(const DkConvDesc* d, int K, int C, int mode = 0)
 {
   DescKey key;
   memset(&key, 0, sizeof(key));
   key.v[0] = d->c; key.v[1] = d->h; key.v[2] = d->w; key.v[3] = d->groups;
-  key.v[4] = d->size; key.v[5] = d->dilation;
+  key.v[4] = d->size; key.v[5] = d->dilation; key.v[6] = mode;
+  if (mode == 1)
+  {
+    key.v[7] = d->stride_x; key.v[8] = d->stride_y; key.v[9] = d->n;
+  }
   int dev = cuda_get_device();
   std::lock_guard<std::mutex> lk(g_mu);
   Plan& pl = g_plans[std::make_pair(dev, key)];
@@ -538,11 +571,22 @@ Plan& get_plan(const DkConvDesc* d, int K, int C)
     const int ss = d->size * d->size;
     for (int k = 0; k < kpad; ++k)
     {
-      if (k < K)
+      if (k < K && mode == 0)
       {
         const int c = k / ss, t = k % ss, kh = t / d->size, kw = t % d->size;
         h[k].x = (c * d->h * d->w + kh * d->dilation * d->w + kw * d->dilation) * 4;  // bytes
         h[k].y = 31 - t;  // left shift that brings tap t's bit to the sign position
+      }
+      else if (k < K)
+      {
+        // data gradient: k = (m, kh, kw) over the delta tensor [n/groups][oh][ow]
+        const int keff = d->dilation * (d->size - 1) + 1, pd = d->pad * d->dilation;
+        const int oh = (d->h + 2 * pd - keff) / d->stride_y + 1;
+        const int ow = (d->w + 2 * pd - keff) / d->stride_x + 1;
+        const int m = k / ss, t = k % ss, kh = t / d->size, kw = t % d->size;
+        const int uy = (kh * d->dilation) / d->stride_y, ux = (kw * d->dilation) / d->stride_x;
+        h[k].x = (m * oh * ow - uy * ow - ux) * 4;
+        h[k].y = 31 - t;
       }
       else
       {
@@ -725,6 +769,7 @@ int dk_conv_forward_cfg(const DkConvDesc* d, const float* x, const float* weight
     a.tiles_m = (M + c.bm - 1) / c.bm;
     a.tiles_n = (a.N + c.bn - 1) / c.bn;
     a.groups = d->groups;
+    a.mode = 0;
     const long long nblk = (long long)a.tiles_m * a.tiles_n * d->groups;
     if (nblk > 0x7fffffffLL)
     {
@@ -751,6 +796,81 @@ int dk_conv_forward_cfg(const DkConvDesc* d, const float* x, const float* weight
       pr.gflop = 2.0 * (double)M * K * d->groups * (double)a.N / 1e9;
       g_prof.push_back(pr);
     }
+  }
+  return 0;
+}
+
+
+// Data gradient of the convolution (the reference's gemm(1,0) + col2im_gpu_kernel_ext,
+// src/convolutional_kernels.cu:784-812; CPU: gemm TN + col2im_cpu_ext,
+// src/convolutional_layer.cpp:1358-1376) as ONE implicit GEMM with the same
+// kernel: prev_delta[b][c][iy][ix] = sum_{m,kh,kw} Wt[c][(m,kh,kw)] * delta[b][m][oy][ox]
+// with (oy, ox) = ((iy + pad - kh*dil)/stride, ...) where divisible.  No col
+// buffer, no atomics; prev_delta is OVERWRITTEN (col2im_cpu_ext zero-fills its
+// target first, src/col2im.c:70 -- SURVEY quirk 4).  `wt` is the per-group
+// transposed weight matrix produced by dk_transpose_weights.
+extern "C" int dk_conv_backward_data(const DkConvDesc* d, const float* delta, const float* wt,
+    float* prev_delta, void* stream)
+{
+  if (!d || !delta || !wt || !prev_delta || d->groups < 1 || d->size * d->size > 31)
+  {
+    fprintf(stderr, "dk_conv_backward_data: invalid arguments\n");
+    return 1;
+  }
+  const int pad = d->pad * d->dilation;
+  const int keff = d->dilation * (d->size - 1) + 1;
+  const int OHd = out_dim(d->h, pad, keff, d->stride_y);
+  const int OWd = out_dim(d->w, pad, keff, d->stride_x);
+  const int Cg = d->c / d->groups, Mg = d->n / d->groups, ss = d->size * d->size;
+  const int K = Mg * ss;
+  const size_t delta_img = (size_t)d->n * OHd * OWd;
+  const size_t in_img = (size_t)d->c * d->h * d->w;
+  int chunk = d->batch;
+  const size_t lim_in = (size_t)1 << 29, lim_out = (size_t)1 << 30;
+  if (delta_img * chunk >= lim_in || in_img * chunk >= lim_out)
+  {
+    chunk = (int)((lim_in - 1) / delta_img);
+    const int c2 = (int)((lim_out - 1) / in_img);
+    if (c2 < chunk)
+      chunk = c2;
+    if (chunk < 1)
+    {
+      fprintf(stderr, "dk_conv_backward_data: one image exceeds the addressing window\n");
+      return 1;
+    }
+  }
+  Plan& pl = get_plan(d, K, Mg, 1);
+  hipStream_t st = stream ? (hipStream_t)stream : get_cuda_stream();
+  for (int b0 = 0; b0 < d->batch; b0 += chunk)
+  {
+    const int nb = (d->batch - b0 < chunk) ? d->batch - b0 : chunk;
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = delta + (size_t)b0 * delta_img;
+    a.w = wt;
+    a.bias = nullptr;
+    a.y = prev_delta + (size_t)b0 * in_img;
+    a.ktab = pl.ktab;
+    a.x_bytes = (unsigned)(delta_img * nb * sizeof(float));
+    a.w_bytes = (unsigned)((size_t)Cg * K * sizeof(float));
+    a.y_bytes = (unsigned)(in_img * nb * sizeof(float));
+    a.C = Mg; a.H = OHd; a.W = OWd; a.Ctot = d->n;
+    a.M = Cg; a.Mtot = d->c; a.K = K;
+    a.OH = d->h; a.OW = d->w; a.OHW = d->h * d->w;
+    a.N = nb * d->h * d->w;
+    a.size = d->size; a.stride_x = d->stride_x; a.stride_y = d->stride_y;
+    a.pad = pad; a.dil = d->dilation;
+    a.act = DK_LINEAR;
+    a.mode = 1;
+    const int ci = pick_cfg(Cg, a.N, d->groups);
+    const TileCfg& c = g_cfgs[ci];
+    a.tiles_m = (Cg + c.bm - 1) / c.bm;
+    a.tiles_n = (a.N + c.bn - 1) / c.bn;
+    a.groups = d->groups;
+    const long long nblk = (long long)a.tiles_m * a.tiles_n * d->groups;
+    const bool avec = (K % 4 == 0) && (((uintptr_t)wt & 15) == 0);
+    hipLaunchKernelGGL(c.kernel[avec ? 1 : 0], dim3((unsigned)nblk), dim3(c.threads), 0, st, a);
+    CHECK_HIP(hipPeekAtLastError());
   }
   return 0;
 }

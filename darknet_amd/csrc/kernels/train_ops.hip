@@ -1,0 +1,459 @@
+// train_ops.hip -- the bandwidth-bound kernels of the training path: batch-norm
+// forward (batch statistics) and backward, activation gradients, bias gradient,
+// backward of maxpool / route / shortcut / upsample / yolo, the fused SGD update
+// and the weight transpose used by the data-gradient convolution.
+//
+// Parity target = the reference's CPU functions (the GPU twins differ in eps,
+// rolling momentum and variance denominator -- SURVEY.md section 8a quirks 1-2):
+//   mean_cpu / variance_cpu / normalize_cpu      src/blas.c:164-218
+//   ForwardBatchnormLayer                        src/batchnorm_layer.cpp:206-238
+//   backward_scale_cpu / mean_delta_cpu / variance_delta_cpu / normalize_delta_cpu
+//                                                src/batchnorm_layer.cpp:92-165
+//   gradient_array / gradient_array_mish         src/activations.c:401-452
+//   backward_bias                                src/convolutional_layer.cpp:946-957
+//   BackwardMaxpoolLayer                         src/maxpool_layer.cpp:312-324
+//   BackwardRouteLayer                           src/route_layer.c:106-122
+//   BackwardShortcutCpu                          src/blas.c:101-129
+//   upsample_cpu (forward = 0)                   src/blas.c:382-406
+//   UpdateConvolutionalLayer                     src/convolutional_layer.cpp:1382-1399
+// Per-channel reductions run one workgroup per channel: wave shuffles, then an
+// LDS tree (the order of the fp32 sums differs from the CPU's sequential loop;
+// covered by the 1e-4 tolerance).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "dark_hip.h"
+#include "dk_kernels.h"
+#include "dk_device_math.h"
+
+namespace
+{
+inline hipStream_t S(void* s) { return s ? (hipStream_t)s : get_cuda_stream(); }
+inline int grid_for(size_t work, int threads = 256)
+{
+  size_t b = (work + threads - 1) / threads;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+constexpr int RT = 512;  // threads per reduction workgroup
+
+__device__ __forceinline__ double block_sum(double v, double* sh)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0)
+    sh[w] = v;
+  __syncthreads();
+  double r = 0;
+  if (threadIdx.x == 0)
+  {
+    for (int i = 0; i < RT / 64; ++i) r += sh[i];
+    sh[0] = r;
+  }
+  __syncthreads();
+  r = sh[0];
+  return r;
+}
+
+// element (b, f, i) of a [batch][filters][spatial] tensor, for a flat per-channel index t
+__device__ __forceinline__ size_t chan_index(size_t t, int f, int filters, int spatial)
+{
+  const size_t b = t / spatial, i = t - b * spatial;
+  return (b * filters + f) * (size_t)spatial + i;
+}
+
+// ---- batch-norm forward -------------------------------------------------------
+__global__ void __launch_bounds__(RT) bn_stats_kernel(const float* __restrict__ x, int batch,
+    int filters, int spatial, float* __restrict__ mean, float* __restrict__ variance,
+    float* __restrict__ rolling_mean, float* __restrict__ rolling_variance)
+{
+  __shared__ double sh[RT / 64];
+  const int f = blockIdx.x;
+  const size_t n = (size_t)batch * spatial;
+  double s = 0;
+  for (size_t t = threadIdx.x; t < n; t += RT) s += x[chan_index(t, f, filters, spatial)];
+  s = block_sum(s, sh);
+  const float scale = 1. / (batch * spatial);       // mean_cpu, blas.c:166
+  const float m = (float)s * scale;
+  double v = 0;
+  for (size_t t = threadIdx.x; t < n; t += RT)
+  {
+    const float d = x[chan_index(t, f, filters, spatial)] - m;
+    v += (double)d * (double)d;                     // pow(x - mean, 2) in double, blas.c:196
+  }
+  v = block_sum(v, sh);
+  if (threadIdx.x == 0)
+  {
+    const float vscale = 1. / (batch * spatial - 1);  // variance_cpu divides by N-1, blas.c:186
+    const float var = (float)v * vscale;
+    mean[f] = m;
+    variance[f] = var;
+    // rolling = .9*rolling + .1*batch: scal_cpu then axpy_cpu, batchnorm_layer.cpp:221-224
+    float rm = rolling_mean[f] * .9f;
+    rm += .1f * m;
+    rolling_mean[f] = rm;
+    float rv = rolling_variance[f] * .9f;
+    rv += .1f * var;
+    rolling_variance[f] = rv;
+  }
+}
+
+// normalize_cpu (eps 1e-6) + scale_bias + add_bias + activation, one pass.
+__global__ void bn_apply_kernel(const float* __restrict__ raw, float* __restrict__ x_save,
+    float* __restrict__ x_norm, float* __restrict__ act_in, float* __restrict__ out,
+    const float* __restrict__ mean, const float* __restrict__ variance,
+    const float* __restrict__ scales, const float* __restrict__ biases, int filters, int spatial,
+    size_t total, int act)
+{
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x)
+  {
+    const int f = (int)((i / spatial) % filters);
+    const float v = raw[i];
+    if (x_save)
+      x_save[i] = v;
+    float xn = (v - mean[f]) / (sqrtf(variance[f] + .000001f));
+    if (x_norm)
+      x_norm[i] = xn;
+    xn = xn * scales[f];
+    xn = xn + biases[f];
+    if (act_in)
+      act_in[i] = xn;
+    out[i] = dk_activate(xn, act);
+  }
+}
+
+// ---- activation gradient -------------------------------------------------------
+__global__ void gradient_kernel(const float* __restrict__ y, const float* __restrict__ act_in,
+    float* __restrict__ delta, size_t n, int act)
+{
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+  {
+    float g;
+    if (act == DK_MISH)
+    {
+      // gradient_array_mish, activations.c:426-452 (float overloads of exp/tanh)
+      const float inp = act_in[i];
+      const float sp = dk_softplus(inp, 20.f);
+      const float grad_sp = 1 - expf(-sp);
+      const float tsp = tanhf(sp);
+      const float grad_tsp = (1 - tsp * tsp) * grad_sp;
+      g = inp * grad_tsp + tsp;
+    }
+    else if (act == DK_LEAKY)
+      g = (y[i] > 0) ? 1 : .1f;
+    else if (act == DK_LOGISTIC)
+      g = (1 - y[i]) * y[i];
+    else if (act == DK_RELU)
+      g = (y[i] > 0);
+    else
+      g = 1;
+    delta[i] *= g;
+  }
+}
+
+// ---- per-channel reductions of the backward pass ----------------------------------
+// mode 0: bias_updates[f] += sum(delta)                      (backward_bias)
+// mode 1: batch-norm: scale_updates[f] += sum(delta*x_norm); bias_updates[f] += sum(delta);
+//         mean_delta[f] = sum(delta*scale) * (-1/sqrt(var+1e-5));
+//         variance_delta[f] = sum(delta*scale*(x-mean)) * (-.5*pow(var+1e-5,-1.5))
+__global__ void __launch_bounds__(RT) chan_reduce_kernel(const float* __restrict__ delta,
+    const float* __restrict__ x, const float* __restrict__ x_norm, const float* __restrict__ mean,
+    const float* __restrict__ variance, const float* __restrict__ scales, int batch, int filters,
+    int spatial, float* __restrict__ bias_updates, float* __restrict__ scale_updates,
+    float* __restrict__ mean_delta, float* __restrict__ variance_delta, int mode)
+{
+  __shared__ double sh[RT / 64];
+  const int f = blockIdx.x;
+  const size_t n = (size_t)batch * spatial;
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  const float sc = mode ? scales[f] : 1.f;
+  const float m = mode ? mean[f] : 0.f;
+  for (size_t t = threadIdx.x; t < n; t += RT)
+  {
+    const size_t idx = chan_index(t, f, filters, spatial);
+    const float d = delta[idx];
+    s0 += d;
+    if (mode)
+    {
+      s1 += d * x_norm[idx];
+      const float ds = d * sc;  // scale_bias(delta, scales) rounds here
+      s2 += ds;
+      s3 += ds * (x[idx] - m);
+    }
+  }
+  s0 = block_sum(s0, sh);
+  if (mode)
+  {
+    s1 = block_sum(s1, sh);
+    s2 = block_sum(s2, sh);
+    s3 = block_sum(s3, sh);
+  }
+  if (threadIdx.x == 0)
+  {
+    if (bias_updates)
+      bias_updates[f] += (float)s0;
+    if (mode)
+    {
+      scale_updates[f] += (float)s1;
+      const float var = variance[f];
+      float md = (float)s2;
+      md *= (-1. / sqrtf(var + .00001f));
+      mean_delta[f] = md;
+      float vd = (float)s3;
+      vd *= -.5 * powf(var + .00001f, (float)(-3. / 2.));
+      variance_delta[f] = vd;
+    }
+  }
+}
+
+// normalize_delta_cpu, batchnorm_layer.cpp:147-165 (after delta *= scale)
+__global__ void bn_delta_kernel(float* __restrict__ delta, const float* __restrict__ x,
+    const float* __restrict__ mean, const float* __restrict__ variance,
+    const float* __restrict__ mean_delta, const float* __restrict__ variance_delta,
+    const float* __restrict__ scales, int batch, int filters, int spatial, size_t total)
+{
+  const int nb = spatial * batch;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x)
+  {
+    const int f = (int)((i / spatial) % filters);
+    const float ds = delta[i] * scales[f];
+    delta[i] = ds * 1. / (sqrtf(variance[f]) + .00001f) +
+               variance_delta[f] * 2. * (x[i] - mean[f]) / nb + mean_delta[f] / nb;
+  }
+}
+
+// ---- backward of the glue layers ----------------------------------------------------
+__global__ void maxpool_bwd_kernel(const float* __restrict__ delta, const int* __restrict__ indexes,
+    size_t n, float* __restrict__ prev_delta)
+{
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+  {
+    const int idx = indexes[i];
+    if (idx >= 0)
+      atomicAdd(&prev_delta[idx], delta[i]);  // stride-1 SPP windows overlap
+  }
+}
+
+// dst[j*dst_stride + i] += alpha * src[j*src_stride + i]
+__global__ void axpy2d_kernel(const float* __restrict__ src, float* __restrict__ dst, int part,
+    int batch, size_t src_stride, size_t dst_stride, float alpha)
+{
+  const size_t total = (size_t)part * batch;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x)
+  {
+    const int j = (int)(i / part);
+    const int e = (int)(i - (size_t)j * part);
+    dst[j * dst_stride + e] += alpha * src[j * src_stride + e];
+  }
+}
+
+__global__ void shortcut_bwd_kernel(const float* __restrict__ delta, size_t n,
+    float* __restrict__ prev_delta, float* __restrict__ from_delta)
+{
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+  {
+    const float d = delta[i];
+    prev_delta[i] += d;
+    from_delta[i] += d;
+  }
+}
+
+// prev[in] += scale*out over the stride x stride block, in the reference's (j, i) order
+__global__ void upsample_bwd_kernel(const float* __restrict__ delta, float* __restrict__ prev, int w,
+    int h, size_t planes, int stride, float scale)
+{
+  const size_t total = planes * (size_t)h * w;
+  const int ow = w * stride;
+  for (size_t id = blockIdx.x * (size_t)blockDim.x + threadIdx.x; id < total;
+       id += (size_t)gridDim.x * blockDim.x)
+  {
+    const int x = (int)(id % w);
+    const size_t t = id / w;
+    const int y = (int)(t % h);
+    const size_t pl = t / h;
+    float acc = prev[id];
+    const float* o = delta + (pl * h * stride + (size_t)y * stride) * ow + (size_t)x * stride;
+    for (int j = 0; j < stride; ++j)
+      for (int i = 0; i < stride; ++i) acc += scale * o[(size_t)j * ow + i];
+    prev[id] = acc;
+  }
+}
+
+// ---- SGD with momentum and decay, one pass (UpdateConvolutionalLayer) -------------------
+__global__ void sgd_kernel(float* __restrict__ w, float* __restrict__ wu, size_t n, float decay_b,
+    float lr_b, float momentum, int use_decay)
+{
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+  {
+    float u = wu[i];
+    float x = w[i];
+    if (use_decay)
+      u += decay_b * x;   // axpy(-decay*batch, weights -> weight_updates)
+    x += lr_b * u;        // axpy(lr/batch, weight_updates -> weights)
+    u *= momentum;        // scal(momentum, weight_updates)
+    w[i] = x;
+    wu[i] = u;
+  }
+}
+
+// Wt[c][(m, t)] = W[m][c][t]  (t = kh*size + kw), per group
+__global__ void transpose_w_kernel(const float* __restrict__ w, float* __restrict__ wt, int M, int C,
+    int ss, size_t total)
+{
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x)
+  {
+    const int t = (int)(i % ss);
+    const size_t r = i / ss;
+    const int m = (int)(r % M);
+    const int c = (int)(r / M);
+    wt[i] = w[((size_t)m * C + c) * ss + t];
+  }
+}
+}  // namespace
+
+extern "C" int dk_bn_forward_train(const float* raw, float* x_save, float* x_norm, float* act_in,
+    float* out, float* mean, float* variance, float* rolling_mean, float* rolling_variance,
+    const float* scales, const float* biases, int batch, int filters, int spatial, int activation,
+    int train, void* stream)
+{
+  const size_t total = (size_t)batch * filters * spatial;
+  if (total == 0)
+    return 0;
+  if (train)
+  {
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(filters), dim3(RT), 0, S(stream), raw, batch, filters,
+        spatial, mean, variance, rolling_mean, rolling_variance);
+    CHECK_HIP(hipPeekAtLastError());
+  }
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total)), dim3(256), 0, S(stream), raw,
+      train ? x_save : nullptr, train ? x_norm : nullptr, act_in, out, train ? mean : rolling_mean,
+      train ? variance : rolling_variance, scales, biases, filters, spatial, total, activation);
+  CHECK_HIP(hipPeekAtLastError());
+  return 0;
+}
+
+extern "C" int dk_gradient_array(const float* y, const float* activation_input, float* delta,
+    size_t n, int activation, void* stream)
+{
+  if (n == 0 || activation == DK_LINEAR)
+    return 0;
+  if (activation == DK_MISH && !activation_input)
+  {
+    fprintf(stderr, "dk_gradient_array: mish needs the saved pre-activation\n");
+    return 1;
+  }
+  hipLaunchKernelGGL(gradient_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), y,
+      activation_input, delta, n, activation);
+  CHECK_HIP(hipPeekAtLastError());
+  return 0;
+}
+
+extern "C" int dk_backward_bias(float* bias_updates, const float* delta, int batch, int n, int size,
+    void* stream)
+{
+  if ((size_t)batch * n * size == 0)
+    return 0;
+  hipLaunchKernelGGL(chan_reduce_kernel, dim3(n), dim3(RT), 0, S(stream), delta, nullptr, nullptr,
+      nullptr, nullptr, nullptr, batch, n, size, bias_updates, nullptr, nullptr, nullptr, 0);
+  CHECK_HIP(hipPeekAtLastError());
+  return 0;
+}
+
+extern "C" int dk_bn_backward(float* delta, const float* x, const float* x_norm, const float* mean,
+    const float* variance, const float* scales, float* mean_delta, float* variance_delta,
+    float* scale_updates, float* bias_updates, int batch, int filters, int spatial, void* stream)
+{
+  const size_t total = (size_t)batch * filters * spatial;
+  if (total == 0)
+    return 0;
+  hipLaunchKernelGGL(chan_reduce_kernel, dim3(filters), dim3(RT), 0, S(stream), delta, x, x_norm,
+      mean, variance, scales, batch, filters, spatial, bias_updates, scale_updates, mean_delta,
+      variance_delta, 1);
+  CHECK_HIP(hipPeekAtLastError());
+  hipLaunchKernelGGL(bn_delta_kernel, dim3(grid_for(total)), dim3(256), 0, S(stream), delta, x,
+      mean, variance, mean_delta, variance_delta, scales, batch, filters, spatial, total);
+  CHECK_HIP(hipPeekAtLastError());
+  return 0;
+}
+
+extern "C" int dk_maxpool_backward(const float* delta, const int* indexes, size_t n,
+    float* prev_delta, void* stream)
+{
+  if (n == 0)
+    return 0;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), delta, indexes,
+      n, prev_delta);
+  CHECK_HIP(hipPeekAtLastError());
+  return 0;
+}
+
+extern "C" int dk_route_backward(const float* delta, int outputs, int offset, int input_size,
+    int groups, int group_id, int batch, float* src_delta, void* stream)
+{
+  const int part = input_size / groups;
+  if (part == 0 || batch == 0)
+    return 0;
+  hipLaunchKernelGGL(axpy2d_kernel, dim3(grid_for((size_t)part * batch)), dim3(256), 0, S(stream),
+      delta + offset, src_delta + (size_t)part * group_id, part, batch, (size_t)outputs,
+      (size_t)input_size, 1.0f);
+  CHECK_HIP(hipPeekAtLastError());
+  return 0;
+}
+
+extern "C" int dk_shortcut_backward(const float* delta, size_t n, float* prev_delta,
+    float* from_delta, void* stream)
+{
+  if (n == 0)
+    return 0;
+  hipLaunchKernelGGL(shortcut_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), delta, n,
+      prev_delta, from_delta);
+  CHECK_HIP(hipPeekAtLastError());
+  return 0;
+}
+
+extern "C" int dk_upsample_backward(const float* delta, int w, int h, int c, int batch, int stride,
+    float scale, float* prev_delta, void* stream)
+{
+  const size_t planes = (size_t)c * batch;
+  if (planes * h * w == 0)
+    return 0;
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(planes * h * w)), dim3(256), 0, S(stream),
+      delta, prev_delta, w, h, planes, stride, scale);
+  CHECK_HIP(hipPeekAtLastError());
+  return 0;
+}
+
+extern "C" int dk_sgd_update(float* weights, float* weight_updates, size_t n, int batch,
+    float learning_rate, float momentum, float decay, int use_decay, void* stream)
+{
+  if (n == 0)
+    return 0;
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), weights,
+      weight_updates, n, -decay * batch, learning_rate / batch, momentum, use_decay);
+  CHECK_HIP(hipPeekAtLastError());
+  return 0;
+}
+
+extern "C" int dk_transpose_weights(const float* w, float* wt, int M, int C, int size, void* stream)
+{
+  const size_t total = (size_t)M * C * size * size;
+  if (total == 0)
+    return 0;
+  hipLaunchKernelGGL(transpose_w_kernel, dim3(grid_for(total)), dim3(256), 0, S(stream), w, wt, M,
+      C, size * size, total);
+  CHECK_HIP(hipPeekAtLastError());
+  return 0;
+}

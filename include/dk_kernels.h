@@ -111,6 +111,60 @@ DK_API int dk_copy(size_t n, const float* x, float* y, void* stream);
 DK_API int dk_axpy(size_t n, float alpha, const float* x, float* y, void* stream);
 DK_API int dk_scal(size_t n, float alpha, float* x, void* stream);
 
+/* ---- training path ------------------------------------------------------- */
+
+/* Conv GEMM stage + batch-norm with batch statistics (ForwardBatchnormLayerGpu,
+ * src/batchnorm_layer.cpp:268-322, with the CPU path's numerics: variance / (N-1),
+ * eps 1e-6, rolling = .9*rolling + .1*batch): `raw` is the convolution output
+ * without bias (dk_conv_forward with biases = NULL, LINEAR); when train != 0 the
+ * batch mean/variance are computed, the rolling statistics updated, x (= raw) and
+ * x_norm saved; then out = act(x_norm*scale + bias), activation_input (may be
+ * NULL) receives the pre-activation.  train == 0 normalises with the rolling
+ * statistics. */
+DK_API int dk_bn_forward_train(const float* raw, float* x_save, float* x_norm,
+    float* activation_input, float* out, float* mean, float* variance, float* rolling_mean,
+    float* rolling_variance, const float* scales, const float* biases, int batch, int filters,
+    int spatial, int activation, int train, void* stream);
+/* gradient_array_ongpu / gradient_array_mish_ongpu, src/activation_kernels.cu:383-503:
+ * delta *= f'(.), evaluated on the output y (mish: on the saved pre-activation). */
+DK_API int dk_gradient_array(const float* y, const float* activation_input, float* delta,
+    size_t n, int activation, void* stream);
+/* backward_bias_gpu, src/convolutional_kernels.cu:37-67: bias_updates[f] += sum delta */
+DK_API int dk_backward_bias(float* bias_updates, const float* delta, int batch, int n, int size,
+    void* stream);
+/* BackwardBatchnormLayerGpu, src/batchnorm_layer.cpp:324-374 with the CPU eps values
+ * (1e-5): scale_updates += sum(delta*x_norm), bias_updates += sum(delta) (may be NULL),
+ * delta <- normalised-delta.  mean_delta / variance_delta are scratch [filters]. */
+DK_API int dk_bn_backward(float* delta, const float* x, const float* x_norm, const float* mean,
+    const float* variance, const float* scales, float* mean_delta, float* variance_delta,
+    float* scale_updates, float* bias_updates, int batch, int filters, int spatial, void* stream);
+/* Weight gradient: weight_updates[m][k] += sum_n delta[m][n]*im2col(x)[k][n] (wgrad half of
+ * BackwardConvolutionalLayerGpu, src/convolutional_kernels.cu:757-781). */
+DK_API int dk_conv_backward_weights(const DkConvDesc* d, const float* x, const float* delta,
+    float* weight_updates, void* stream);
+/* Data gradient: prev_delta = col2im(W^T * delta), overwriting (dgrad half, :784-812).
+ * wt = dk_transpose_weights(weights). */
+DK_API int dk_conv_backward_data(const DkConvDesc* d, const float* delta, const float* wt,
+    float* prev_delta, void* stream);
+/* wt[g][c][(m,kh,kw)] = w[g][m][c][kh][kw]; call per group with M = n/groups, C = c/groups */
+DK_API int dk_transpose_weights(const float* w, float* wt, int M, int C, int size, void* stream);
+/* backward_maxpool_layer_kernel, src/maxpool_layer_kernels.cu:103-143 (scatter-add by index) */
+DK_API int dk_maxpool_backward(const float* delta, const int* indexes, size_t n,
+    float* prev_delta, void* stream);
+/* one source of BackwardRouteLayerGpu, src/route_layer.c:144-160 */
+DK_API int dk_route_backward(const float* delta, int outputs, int offset, int input_size,
+    int groups, int group_id, int batch, float* src_delta, void* stream);
+/* backward_shortcut_multilayer_kernel with n = 1, src/blas_kernels.cu:980-1034 */
+DK_API int dk_shortcut_backward(const float* delta, size_t n, float* prev_delta,
+    float* from_delta, void* stream);
+/* upsample_kernel forward = 0, src/blas_kernels.cu:1121-1146 */
+DK_API int dk_upsample_backward(const float* delta, int w, int h, int c, int batch, int stride,
+    float scale, float* prev_delta, void* stream);
+/* UpdateConvolutionalLayerGpu's SGD branch (src/convolutional_kernels.cu:895-915) for one
+ * tensor, fused: wu += -decay*batch*w (if use_decay); w += (lr/batch)*wu; wu *= momentum. */
+DK_API int dk_sgd_update(float* weights, float* weight_updates, size_t n, int batch,
+    float learning_rate, float momentum, float decay, int use_decay, void* stream);
+
 /* Profiling hooks used by bench.py (measurement only): when enabled every
  * dk_conv_forward is bracketed by HIP events on its stream; dk_profile_read
  * synchronises and returns per tile-configuration totals.

@@ -196,6 +196,7 @@ struct layer
   int fused_into_prev;   /* shortcut folded into the previous conv's epilogue */
   int fuse_residual_from; /* conv: layer index whose output is added in the epilogue, or -1 */
   int conv_cfg;          /* tile configuration chosen by the autotuner, or -1 */
+  float* injected_delta; /* yolo (tests): host delta used instead of the loss, see DkSetYoloDelta */
 };
 
 struct Network
@@ -239,6 +240,7 @@ struct Network
   /* MI355X-native additions */
   void* graph_exec;      /* hipGraphExec_t of the captured forward, or NULL */
   int graph_batch;
+  float* wt_scratch_gpu; /* transposed weights of the layer whose data gradient is running */
 };
 
 #ifdef __cplusplus
@@ -281,6 +283,31 @@ LIB_API float* GetNetworkOutputGpu(Network* net);
 LIB_API int GetNetworkInputSize(Network* net);
 LIB_API int GetNetworkOutputSize(Network* net);
 LIB_API float GetCurrLr(Network* net);
+
+/* ---- training: src/network.cpp:116-239, src/network_kernels.cu:116-293,
+ *      src/convolutional_kernels.cu:555-921 -------------------------------- */
+LIB_API float TrainNetworkDatum(Network* net, float* x, float* y);
+LIB_API float TrainNetworkDatumGpu(Network* net, float* x, float* y);
+LIB_API void ForwardBackwardNetworkGpu(Network* net, float* x, float* y);
+LIB_API void BackwardNetworkGpu(Network* net, NetworkState state);
+LIB_API void UpdateNetworkGpu(Network* net);
+LIB_API void UpdateNetwork(Network* net);
+LIB_API void BackwardConvolutionalLayerGpu(layer* l, NetworkState state);
+LIB_API void UpdateConvolutionalLayerGpu(layer* l, int batch, float learning_rate,
+    float momentum, float decay, float loss_scale);
+LIB_API void BackwardMaxpoolLayerGpu(layer* l, NetworkState state);
+LIB_API void BackwardRouteLayerGpu(layer* l, NetworkState state);
+LIB_API void BackwardShortcutLayerGpu(layer* l, NetworkState state);
+LIB_API void BackwardUpsampleLayerGpu(layer* l, NetworkState state);
+LIB_API void BackwardYoloLayerGpu(layer* l, NetworkState state);
+/* additive: drive the backward pass from a given yolo-layer delta (host array of
+ * batch*outputs floats, kept by reference) instead of the yolo loss */
+LIB_API void DkSetYoloDelta(Network* net, int layer_index, float* host_delta);
+LIB_API void DkSetMaxIter(Network* net, int max_iter);
+/* D2H copy of a layer tensor: which = 6 delta, 7 weight_updates, 8 bias_updates,
+ * 9 scale_updates, 1 weights, 2 biases, 3 scales, 4 rolling_mean, 5 rolling_variance,
+ * 10 mean, 11 variance; returns the element count or -1 */
+LIB_API long DkLayerPull(Network* net, int i, int which, float* dst, size_t n);
 
 /* ---- post-processing kept as host C++: src/box.cpp:372-447 --------------- */
 LIB_API void NmsSort(Detection* dets, int total, int classes, float thresh,

@@ -18,6 +18,14 @@ import numpy as np
 
 REL = 1e-4
 ATOL_RMS = 1e-5
+# Train mode (batch-norm with BATCH statistics): the reference's mean_cpu /
+# variance_cpu (src/blas.c:164-201) add 86 k ... 3 M fp32 terms sequentially into a
+# float, so its own statistics carry ~1e-5 relative rounding error that no parallel
+# reduction reproduces (the HIP kernels accumulate in double, i.e. are closer to the
+# exact value).  Every activation downstream of a BN layer inherits a shift of
+# ~1e-5..1e-4 x rms; train-mode tensors are therefore compared with
+#     |a - b| <= 1e-4 * |b| + 3e-4 * rms(b)   (the shift compounds over successive BN layers).
+TRAIN_ATOL_RMS = 3e-4  # measured worst over yolov4-tiny train forward (21 BN layers, b=2): 1.05e-4 x rms
 FLOOR_FRAC = ATOL_RMS / REL  # equivalent floor on |b| as a fraction of rms
 
 
