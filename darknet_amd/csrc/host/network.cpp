@@ -591,3 +591,5 @@ extern "C" LIB_API int DkLayerFused(Network* net, int i)
   layer* l = &net->layers[i];
   return l->type == SHORTCUT ? l->fused_into_prev : (l->fuse_residual_from >= 0);
 }
+
+extern "C" LIB_API layer* DkLayerPtr(Network* net, int i) { return &net->layers[i]; }

@@ -162,19 +162,27 @@ void DkSetYoloDelta(Network* net, int i, float* host_delta)
 
 void DkSetMaxIter(Network* net, int max_iter) { net->max_iter = max_iter; }
 
-// called by ForwardYoloLayerGpu in train mode (layers.cpp)
+extern "C" float DkYoloLossHost(const layer* l, int net_w, int net_h, float* out,
+    const float* truth, float* delta);
+
+// called by ForwardYoloLayerGpu in train mode (layers.cpp): the loss lives on the
+// host, as in the reference (src/yolo_layer.cpp:861-881): pull the decoded output,
+// compute delta and cost, push the delta.
 void DkYoloTrainDelta(layer* l, NetworkState state)
 {
-  (void)state;
-  if (!l->injected_delta)
+  const size_t total = (size_t)l->batch * l->outputs;
+  if (l->injected_delta)
   {
-    fprintf(stderr,
-        "darknet_amd: yolo layer %d: the detection loss (reference src/yolo_layer.cpp:413-772, host "
-        "C++) is not part of this build yet; drive the backward pass with DkSetYoloDelta().\n",
-        l->index);
-    exit(EXIT_FAILURE);
+    cuda_push_array(l->delta_gpu, l->injected_delta, total);
+    return;
   }
-  cuda_push_array(l->delta_gpu, l->injected_delta, (size_t)l->batch * l->outputs);
+  if (!state.net->truth)
+    error("yolo loss: no truth supplied (TrainNetworkDatum(net, x, y) with y != NULL)");
+  cuda_pull_array(l->output_gpu, l->output, total);  // synchronises the stream
+  if (!l->delta)
+    l->delta = (float*)xcalloc(total, sizeof(float));
+  *(l->cost) = DkYoloLossHost(l, state.net->w, state.net->h, l->output, state.net->truth, l->delta);
+  cuda_push_array(l->delta_gpu, l->delta, total);
 }
 
 void BackwardNetworkGpu(Network* net, NetworkState state)
@@ -230,7 +238,7 @@ void UpdateNetwork(Network* net) { UpdateNetworkGpu(net); }
 
 void ForwardBackwardNetworkGpu(Network* net, float* x, float* y)
 {
-  (void)y;  // truth is consumed by the (host) yolo loss only
+  net->truth = y;  // consumed by the (host) yolo loss
   if (net->gpu_index < 0)
     error("TrainNetworkDatum: no HIP device (this library has no CPU fallback)");
   if (!net->train)

@@ -299,3 +299,33 @@ def test_tiny_train_step_vs_oracle_and_reference_golden(gpu, tmp_path):
         if l.type == O.CONVOLUTIONAL:
             util.assert_close(pull(i, 1, l.nweights), l.weights, "updated weights layer %d" % i, atol_rms=util.TRAIN_ATOL_RMS)
     net.close()
+
+
+def test_real_train_step_with_host_loss(gpu, tmp_path):
+    """TrainNetworkDatum with truth boxes: the yolo loss runs on the host
+    (csrc/host/yolo_loss.cpp, pinned bit-exactly against the reference on CPU), its
+    delta is pushed and the backward sweep runs.  Cost vs the REAL reference's cost for
+    the same step (golden), weight gradients vs the run driven by the reference's deltas."""
+    g, cfg, wpath, x = train_fixture(tmp_path)
+    L = gpu.lib()
+    L.TrainNetworkDatum.argtypes = [VP, VP, VP]
+    L.TrainNetworkDatum.restype = C.c_float
+    L.DkLayerPull.argtypes = [VP, C.c_int, C.c_int, VP, C.c_size_t]
+    L.DkLayerPull.restype = C.c_long
+    net = netutil.DkNet(gpu, cfg, wpath, train=True)
+    truth = np.ascontiguousarray(g["truth"])
+    cost = L.TrainNetworkDatum(net.p, np.ascontiguousarray(x).ctypes.data, truth.ctypes.data)
+    assert abs(cost - float(g["cost"])) <= 2e-3 * float(g["cost"]), (cost, float(g["cost"]))
+    # yolo deltas produced on the host from the HIP forward vs the reference's deltas
+    for i in range(net.n):
+        f = net.info(i)
+        if f["type"] != O.YOLO:
+            continue
+        n = f["batch"] * f["outputs"]
+        d = np.empty(n, np.float32)
+        assert L.DkLayerPull(net.p, i, 6, d.ctypes.data, n) == n
+        ref = np.zeros(n, np.float32)
+        ref[g["yolo_%d_delta_idx" % i]] = g["yolo_%d_delta_val" % i]
+        assert np.count_nonzero(d) == np.count_nonzero(ref)
+        util.assert_close(d, ref, "yolo %d delta" % i, rel=1e-3, atol_rms=1e-3)
+    net.close()

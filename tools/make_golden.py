@@ -241,6 +241,7 @@ def main():
     gen_net("yolov4", full_heads=False)
     gen_net("yolov4-csp", full_heads=False)
     gen_train()
+    gen_yololoss()
 
 
 def gen_train(name="yolov4-tiny", B=2):
@@ -311,8 +312,50 @@ def gen_train(name="yolov4-tiny", B=2):
     print(f"train_{name}.npz: cost {cost:.4f}, lr {lr:.3e}")
 
 
+def gen_yololoss():
+    """The reference's YOLO loss (ForwardYoloLayer train branch, host C++) on the three
+    nets: sparse deltas and cost of every yolo layer for b = 2 with 5 truths/image."""
+    out = {}
+    boxes = [(.3, .4, .2, .3, 1), (.6, .5, .4, .35, 17), (.8, .2, .1, .15, 60), (.05, .93, .08, .1, 3),
+             (.5, .5, .9, .8, 79)]
+    for name in ("yolov4-tiny", "yolov4", "yolov4-csp"):
+        B = 2
+        cfg_txt = open(os.path.join(ROOT, "cfg", name + ".cfg")).read()
+        cfg_txt = cfg_txt.replace("batch=64", "batch=%d" % B).replace("subdivisions=8", "subdivisions=1")
+        cfg = f"/tmp/_dk_loss_{name}.cfg"
+        open(cfg, "w").write(cfg_txt)
+        net = O.parse_cfg(cfg)
+        convs = [(l.n, l.c // l.groups, l.size, l.batch_normalize) for l in net.layers if l.type == O.CONVOLUTIONAL]
+        wpath = f"/tmp/_dk_{name}.weights"
+        synth.write_weights(wpath, convs, seed=2024)
+        x = synth.make_input(B, net.c, net.h, net.w, seed=12345)
+        truth = np.zeros((B, 90 * 5), np.float32)
+        for b in range(B):
+            for t, box in enumerate(boxes[b:] + boxes[:b]):
+                truth[b, t * 5:(t + 1) * 5] = box
+        rn = reflib.RefNet(cfg, wpath, train=True)
+        assert rn.batch == B
+        rn.L.ref_forward_train(rn.p, fp(x), fp(truth))
+        out[name + "_truth"] = truth
+        for i in range(rn.n):
+            inf = rn.info(i)
+            if inf["type"] != O.YOLO:
+                continue
+            d = rn.arr(i, 6, inf["batch"] * inf["outputs"])
+            nz = np.flatnonzero(d)
+            out[f"{name}_{i}_idx"] = nz.astype(np.int64)
+            out[f"{name}_{i}_val"] = d[nz]
+            out[f"{name}_{i}_cost"] = np.float32(rn.L.ref_layer_cost(rn.p, i))
+            print(name, "yolo", i, "nonzero deltas", nz.size, "cost", rn.L.ref_layer_cost(rn.p, i))
+        rn.close()
+    np.savez_compressed(os.path.join(GOLD, "yololoss.npz"), **out)
+    print("yololoss.npz")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "train":
         gen_train()
+    elif len(sys.argv) > 1 and sys.argv[1] == "yololoss":
+        gen_yololoss()
     else:
         main()
