@@ -511,6 +511,13 @@ void FreeNetwork(Network* net)
   DkInvalidateGraph(net);
   float* last_out = net->layers[net->n - 1].output;
   (void)last_out;
+  if (net->grad_bucket)  // gradients live in caller-owned memory
+    for (int i = 0; i < net->n; ++i)
+    {
+      layer* l = &net->layers[i];
+      if (l->type == CONVOLUTIONAL)
+        l->weight_updates_gpu = l->bias_updates_gpu = l->scale_updates_gpu = nullptr;
+    }
   for (int i = 0; i < net->n; ++i) free_layer(&net->layers[i], false);
   free(net->layers);
   free(net->steps);

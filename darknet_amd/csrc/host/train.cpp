@@ -303,3 +303,57 @@ long DkLayerPull(Network* net, int i, int which, float* dst, size_t n)
   cuda_pull_array(p, dst, cnt);
   return (long)cnt;
 }
+
+
+// ---------------------------------------------------------------------------
+// Data-parallel training support: every replica keeps its
+// gradients (weight_updates, bias_updates, scale_updates of every conv, in layer
+// order) in ONE contiguous fp32 bucket so that a single RCCL all-reduce(sum) over
+// xGMI replaces the reference's host-mediated weight averaging
+// (SyncNetworks, src/network_kernels.cu:366-427).  The bucket is caller-owned
+// device memory (bench/train drivers allocate it through torch so that
+// torch.distributed can reduce it in place).
+// ---------------------------------------------------------------------------
+extern "C" LIB_API size_t DkGradBucketSize(Network* net)
+{
+  size_t n = 0;
+  for (int i = 0; i < net->n; ++i)
+  {
+    layer* l = &net->layers[i];
+    if (l->type == CONVOLUTIONAL && l->weight_updates_gpu)
+      n += (size_t)l->nweights + l->n + (l->scale_updates_gpu ? l->n : 0);
+  }
+  return n;
+}
+
+extern "C" LIB_API void DkAttachGradBucket(Network* net, float* bucket)
+{
+  if (net->gpu_index < 0 || !net->train)
+    error("DkAttachGradBucket: needs a train-mode network on a HIP device");
+  hipStream_t st = get_cuda_stream();
+  size_t off = 0;
+  auto move = [&](float** p, size_t n) {
+    CHECK_HIP(hipMemcpyAsync(bucket + off, *p, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    CHECK_HIP(hipStreamSynchronize(st));
+    cuda_free(*p);
+    *p = bucket + off;
+    off += n;
+  };
+  for (int i = 0; i < net->n; ++i)
+  {
+    layer* l = &net->layers[i];
+    if (l->type != CONVOLUTIONAL || !l->weight_updates_gpu)
+      continue;
+    move(&l->weight_updates_gpu, l->nweights);
+    move(&l->bias_updates_gpu, l->n);
+    if (l->scale_updates_gpu)
+      move(&l->scale_updates_gpu, l->n);
+  }
+  net->grad_bucket = bucket;
+}
+
+// B = batch * subdivisions in the update; with R replicas set subdivisions = R
+// (each replica contributes one sub-batch, exactly the reference's accumulation
+// over subdivisions).
+extern "C" LIB_API void DkSetSubdivisions(Network* net, int subdiv) { net->subdiv = subdiv; }
+extern "C" LIB_API void DkAdvanceIteration(Network* net) { net->curr_iter++; }

@@ -241,6 +241,7 @@ struct Network
   void* graph_exec;      /* hipGraphExec_t of the captured forward, or NULL */
   int graph_batch;
   float* wt_scratch_gpu; /* transposed weights of the layer whose data gradient is running */
+  float* grad_bucket;    /* caller-owned contiguous gradient bucket (DkAttachGradBucket), or NULL */
 };
 
 #ifdef __cplusplus
@@ -304,6 +305,13 @@ LIB_API void BackwardYoloLayerGpu(layer* l, NetworkState state);
  * batch*outputs floats, kept by reference) instead of the yolo loss */
 LIB_API void DkSetYoloDelta(Network* net, int layer_index, float* host_delta);
 LIB_API void DkSetMaxIter(Network* net, int max_iter);
+/* data-parallel training: all conv gradients in one caller-owned device bucket
+ * (weight_updates, bias_updates, scale_updates per conv, layer order) that the
+ * caller all-reduces (RCCL) between TrainNetworkDatum and UpdateNetworkGpu */
+LIB_API size_t DkGradBucketSize(Network* net);
+LIB_API void DkAttachGradBucket(Network* net, float* bucket);
+LIB_API void DkSetSubdivisions(Network* net, int subdiv);
+LIB_API void DkAdvanceIteration(Network* net);
 /* D2H copy of a layer tensor: which = 6 delta, 7 weight_updates, 8 bias_updates,
  * 9 scale_updates, 1 weights, 2 biases, 3 scales, 4 rolling_mean, 5 rolling_variance,
  * 10 mean, 11 variance; returns the element count or -1 */

@@ -329,3 +329,65 @@ def test_real_train_step_with_host_loss(gpu, tmp_path):
         assert np.count_nonzero(d) == np.count_nonzero(ref)
         util.assert_close(d, ref, "yolo %d delta" % i, rel=1e-3, atol_rms=1e-3)
     net.close()
+
+
+def test_two_replicas_with_summed_bucket_equal_subdivisions(gpu, tmp_path):
+    """Multi-GPU equivalence on one GPU: two replicas, each on its half of the batch,
+    gradient buckets summed (what the RCCL all-reduce does), update with B = 2*b  ==
+    one replica run with subdivisions = 2 (the reference's own accumulation)."""
+    g, cfg, wpath, x = train_fixture(tmp_path)
+    L = gpu.lib()
+    for fn, at, rt in (("DkGradBucketSize", [VP], C.c_size_t), ("DkAttachGradBucket", [VP, VP], None),
+                       ("DkSetSubdivisions", [VP, C.c_int], None), ("DkAdvanceIteration", [VP], None),
+                       ("TrainNetworkDatum", [VP, VP, VP], C.c_float), ("UpdateNetworkGpu", [VP], None),
+                       ("DkSetMaxIter", [VP, C.c_int], None), ("DkLayerPull", [VP, C.c_int, C.c_int, VP, C.c_size_t], C.c_long)):
+        getattr(L, fn).argtypes = at
+        getattr(L, fn).restype = rt
+    B = int(g["batch"])
+    one = str(tmp_path / "one.cfg")
+    open(one, "w").write(open(cfg).read().replace("batch=%d" % B, "batch=1"))
+    truth = np.ascontiguousarray(g["truth"])
+    xs = [np.ascontiguousarray(x[i:i + 1]) for i in range(B)]
+    ts = [np.ascontiguousarray(truth[i:i + 1]) for i in range(B)]
+    # (a) one replica, batch=2 subdivisions=2 -> net->batch = 1, two accumulating sub-steps
+    sub = str(tmp_path / "sub.cfg")
+    open(sub, "w").write(open(cfg).read().replace("subdivisions=1", "subdivisions=%d" % B))
+    ref = netutil.DkNet(gpu, sub, wpath, train=True)
+    assert ref.batch == 1
+    L.DkSetMaxIter(ref.p, 1000)
+    for i in range(B):
+        L.TrainNetworkDatum(ref.p, xs[i].ctypes.data, ts[i].ctypes.data)
+    L.DkAdvanceIteration(ref.p)
+    L.UpdateNetworkGpu(ref.p)
+    # (b) two replicas with attached buckets; emulate the all-reduce with axpy
+    reps, buckets = [], []
+    for i in range(B):
+        r = netutil.DkNet(gpu, one, wpath, train=True)
+        n = L.DkGradBucketSize(r.p)
+        b = gpu.DeviceArray(np.zeros(n, np.float32))
+        L.DkAttachGradBucket(r.p, b.ptr)
+        L.DkSetSubdivisions(r.p, B)
+        L.DkSetMaxIter(r.p, 1000)
+        reps.append(r)
+        buckets.append(b)
+    for i in range(B):
+        L.TrainNetworkDatum(reps[i].p, xs[i].ctypes.data, ts[i].ctypes.data)
+    total = buckets[0].numpy() + buckets[1].numpy()
+    for b in buckets:
+        L.cuda_push_array(b.ptr, total.ctypes.data, total.size)
+    for r in reps:
+        L.DkAdvanceIteration(r.p)
+        L.UpdateNetworkGpu(r.p)
+
+    def weights(net, i, n):
+        out = np.empty(n, np.float32)
+        assert L.DkLayerPull(net.p, i, 1, out.ctypes.data, n) == n
+        return out
+    for i in range(ref.n):
+        f = ref.info(i)
+        if f["type"] == O.CONVOLUTIONAL:
+            a, b0, b1 = weights(ref, i, f["nweights"]), weights(reps[0], i, f["nweights"]), weights(reps[1], i, f["nweights"])
+            assert np.array_equal(b0, b1), "replicas diverged"
+            util.assert_close(b0, a, "weights after the step, layer %d" % i, rel=1e-5, atol_rms=1e-6)
+    for r in reps + [ref]:
+        r.close()
