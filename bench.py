@@ -43,6 +43,21 @@ CFG = "yolov4"
 BATCH_PER_GPU = 16
 
 
+def pmc_traffic_for(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary
+    (profiles/*pmc_traffic*.json, produced by tools/pmc_traffic.sh on this workload);
+    None when no summary names the kernel."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
+        try:
+            for r in json.load(open(f)):
+                if kernel in r["kernel"]:
+                    return r["hbm_bytes_per_launch"]
+        except Exception:
+            pass
+    return None
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -133,10 +148,14 @@ def main():
         tot_ms = sum(r[0] for r in rows)
         tot_gf = sum(r[2] for r in rows)
         achieved = gflop / ms  # GFLOP / ms = TFLOP/s
+        kname = L.dk_conv_kernel_name(ci).decode()
+        traffic = pmc_traffic_for(kname)
         roofline = {
             "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-            "kernel": L.dk_conv_kernel_name(ci).decode(),
+            "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+            "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate "
+                            "rocprofv3 --pmc passes of this command: tools/pmc_traffic.sh -> profiles/)",
+            "kernel": kname,
             "launches_per_step": launches / prof_steps,
             "gflop_per_launch": gflop / launches, "avg_launch_ms": ms / launches,
             "all_conv_kernels": {"achieved": tot_gf / tot_ms, "frac": tot_gf / tot_ms / FP32_MFMA_PEAK_TFLOPS,

@@ -243,8 +243,44 @@ void DkPlanInference(Network* net)
   // 3. per-layer tile choice
   const char* e = getenv("DK_AUTOTUNE");
   const bool tune = e ? atoi(e) != 0 : g_dk_autotune != 0;
-  if (tune)
+  // DK_TUNE_FILE: reuse a previous run's per-layer choice (profiling runs then
+  // contain no tuning launches); written when absent.
+  const char* tf = getenv("DK_TUNE_FILE");
+  bool loaded = false;
+  if (tune && tf)
+  {
+    if (FILE* f = fopen(tf, "r"))
+    {
+      int n = 0, b = 0;
+      if (fscanf(f, "%d %d", &n, &b) == 2 && n == net->n && b == net->batch)
+      {
+        loaded = true;
+        for (int i = 0; i < net->n; ++i)
+        {
+          int c = -1;
+          if (fscanf(f, "%d", &c) != 1)
+          {
+            loaded = false;
+            break;
+          }
+          if (net->layers[i].type == CONVOLUTIONAL)
+            net->layers[i].conv_cfg = c;
+        }
+      }
+      fclose(f);
+    }
+  }
+  if (tune && !loaded)
+  {
     autotune_convs(net);
+    if (tf)
+      if (FILE* f = fopen(tf, "w"))
+      {
+        fprintf(f, "%d %d\n", net->n, net->batch);
+        for (int i = 0; i < net->n; ++i) fprintf(f, "%d\n", net->layers[i].conv_cfg);
+        fclose(f);
+      }
+  }
   DkInvalidateGraph(net);
 }
 

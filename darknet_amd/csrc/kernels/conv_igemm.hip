@@ -478,6 +478,8 @@ const TileCfg g_cfgs[] = {
     DK_CFG(32, 128, 16, 32, 32, 0.80f),
     DK_CFG(256, 128, 16, 64, 64, 0.98f),
     DK_CFG(64, 256, 16, 32, 128, 0.95f),
+    DK_CFG(128, 64, 32, 64, 32, 0.97f),
+    DK_CFG(64, 64, 32, 32, 32, 0.92f),
 };
 const int g_ncfg = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
 
