@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="images per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--half", action="store_true", help="fp16 operands / fp32 accumulate on the layers the reference's rule admits (config C5)")
     args = ap.parse_args()
 
     import torch  # device sync + torch.distributed (RCCL) only
@@ -89,6 +90,9 @@ def main():
     torch.cuda.set_device(ctx.local_rank)
     L.cuda_set_device(ctx.local_rank)
 
+    if args.half:
+        L.DkSetHalf.argtypes = [C.c_int]
+        L.DkSetHalf(1)
     tmp = tempfile.mkdtemp(prefix="dkbench%d_" % ctx.rank)
     wpath = os.path.join(tmp, args.cfg + ".weights")
     netapi.synth_weights_for(dk, args.cfg, wpath, seed=2024)
@@ -175,14 +179,15 @@ def main():
 
     if ctx.rank == 0:
         res = {
-            "metric": "images/sec YOLOv4 608x608 fwd",
+            "metric": "images/sec YOLOv4 608x608 fwd" if args.cfg == "yolov4" else "images/sec %s fwd" % args.cfg,
             "value": value, "unit": "images/sec", "n_gpus": ctx.world,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * tmax / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s.cfg 608x608 batch=%d/GPU forward, BN folded, bias+mish/leaky fused "
-                                   "(BASELINE configs[2])" % (args.cfg, args.batch),
+            "dtype": "f16 operands / f32 accumulate (eligible 3x3 layers), f32 elsewhere" if args.half else "f32", "data": "synthetic",
+            "config": {"workload": "%s.cfg %dx%d batch=%d/GPU forward, BN folded, bias+mish/leaky fused%s"
+                                   % (args.cfg, net.w, net.h, args.batch,
+                                      " (BASELINE configs[2])" if (args.cfg == "yolov4" and args.batch == 16 and not args.half) else ""),
                        "global_batch": args.batch * ctx.world,
                        "parallelism": "batch-sharded replicas x%d, no data-path collective" % ctx.world},
             "frac_of_fp32_mfma_roofline": value * 128.459e9 / (ctx.world * FP32_MFMA_PEAK_TFLOPS * 1e12)

@@ -205,6 +205,13 @@ void ForwardConvolutionalLayerGpu(layer* l, NetworkState state)
     residual = state.net->layers[l->fuse_residual_from].output_gpu;
   }
   float* act_in = (state.train && l->activation_input_gpu) ? l->activation_input_gpu : nullptr;
+  if (state.net->cudnn_half && !state.train && dk_conv_half_eligible(&d, l->index))
+  {
+    if (dk_conv_forward_half(&d, state.input, l->weights_gpu, l->biases_gpu, out, residual, act_in,
+            get_cuda_stream()))
+      error("ForwardConvolutionalLayerGpu (fp16 operands) failed");
+    return;
+  }
   if (dk_conv_forward_cfg(&d, state.input, l->weights_gpu, l->biases_gpu, out, residual, act_in,
           get_cuda_stream(), l->conv_cfg))
     error("ForwardConvolutionalLayerGpu failed");

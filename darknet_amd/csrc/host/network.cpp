@@ -31,6 +31,8 @@ void DkConvPrepare(layer* l);
 void DkSetFusion(int on) { g_dk_fusion = on; }
 void DkSetGraph(int on) { g_dk_graph = on; }
 void DkSetAutotune(int on) { g_dk_autotune = on; }
+int g_dk_half = -1;
+void DkSetHalf(int on) { g_dk_half = on; }
 extern "C" LIB_API void DkSetPullHeads(int on) { g_dk_pull_heads = on; }
 
 // ---------------------------------------------------------------------------
@@ -171,7 +173,9 @@ static void autotune_convs(Network* net)
   for (int i = 0; i < net->n; ++i)
   {
     layer* l = &net->layers[i];
-    if (l->type == CONVOLUTIONAL && !l->batch_normalize)
+    DkConvDesc hd = {l->batch, l->c, l->h, l->w, l->n, l->groups, l->size, l->stride_x, l->stride_y, l->dilation, l->pad, (int)l->activation};
+    const bool half_layer = net->cudnn_half && l->type == CONVOLUTIONAL && dk_conv_half_eligible(&hd, i);
+    if (l->type == CONVOLUTIONAL && !l->batch_normalize && !half_layer)
     {
       std::vector<int> key = {l->batch, l->c, l->h, l->w, l->n, l->groups, l->size, l->stride_x,
           l->stride_y, l->dilation, l->pad, (int)l->activation, l->fuse_residual_from >= 0};
@@ -215,6 +219,10 @@ static void autotune_convs(Network* net)
 
 void DkPlanInference(Network* net)
 {
+  {
+    const char* eh = getenv("DK_HALF");
+    net->cudnn_half = g_dk_half >= 0 ? g_dk_half : (eh ? atoi(eh) != 0 : 0);
+  }
   // 1. conv + shortcut(linear) epilogue fusion
   for (int i = 1; i < net->n; ++i)
   {

@@ -57,6 +57,16 @@ DK_API int dk_conv_forward(const DkConvDesc* d, const float* x, const float* wei
     const float* biases, float* y, const float* residual,
     float* activation_input, void* stream);
 
+/* fp16-operand variant (BASELINE config C5; reference: the CUDNN_HALF branch,
+ * src/convolutional_kernels.cu:357-456): x and weights are rounded to fp16
+ * (round-to-nearest-even) while being staged, products accumulate in fp32 on
+ * v_mfma_f32_32x32x16_f16, bias/activation/output stay fp32.  Only for layers
+ * the reference's rule admits (dk_conv_half_eligible: size > 1, c % 8 == 0,
+ * n % 8 == 0, groups == 1, not the network's first layer). */
+DK_API int dk_conv_forward_half(const DkConvDesc* d, const float* x, const float* weights,
+    const float* biases, float* y, const float* residual, float* activation_input, void* stream);
+DK_API int dk_conv_half_eligible(const DkConvDesc* d, int layer_index);
+
 /* Tile-configuration control for tuning: cfg >= 0 forces one of the compiled
  * tile shapes for every subsequent dk_conv_forward (-1 = heuristic).  Returns
  * the number of compiled configurations. */

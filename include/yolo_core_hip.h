@@ -353,6 +353,9 @@ LIB_API Detection* GetNetworkBoxesBatch(Network* net, int b, float thresh, int* 
 LIB_API void DkSetFusion(int on);
 LIB_API void DkSetGraph(int on);
 LIB_API void DkSetAutotune(int on);
+/* fp16-operand convolutions for the layers the reference's CUDNN_HALF rule admits
+ * (sets net->cudnn_half at the next load; also env DK_HALF=1) */
+LIB_API void DkSetHalf(int on);
 
 /* Flat helpers for FFI callers (ctypes, tests, bench.py) */
 LIB_API Network* DkNetworkCreate(void);            /* calloc'ed Network */

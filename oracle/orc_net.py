@@ -302,9 +302,18 @@ def load_network(cfg, weights, batch=1):
 
 
 # -------------------------------------------------------------------- forward
-def forward(net, x, keep=None, upto=None):
+def half_eligible(l):
+    """The reference's fp16 rule, src/convolutional_kernels.cu:361-365."""
+    return (l.type == CONVOLUTIONAL and l.size > 1 and l.c % 8 == 0 and l.n % 8 == 0 and
+            l.groups == 1 and l.index != 0)
+
+
+def forward(net, x, keep=None, upto=None, half=False):
     """ForwardNetwork in inference mode (BN folded).  x: float32 [batch, c*h*w].
-    Every layer's output is kept in l.output (as the reference does)."""
+    Every layer's output is kept in l.output (as the reference does).
+    half=True: the oracle of BASELINE config C5 -- the reference has no CPU fp16
+    path, so it is the CPU fp32 path with the eligible
+    layers' inputs and weights pre-rounded to fp16 (round-to-nearest-even)."""
     L = lib()
     x = np.ascontiguousarray(x, np.float32).reshape(net.batch, -1)
     ws = np.zeros(net.workspace, np.float32)
@@ -316,7 +325,11 @@ def forward(net, x, keep=None, upto=None):
         out = np.zeros((B, l.outputs), np.float32)
         if l.type == CONVOLUTIONAL:
             assert not l.batch_normalize, "inference oracle expects fused BN"
-            L.orc_conv_forward_fused(fptr(inp), fptr(l.weights), fptr(l.biases),
+            cin, cw = inp, l.weights
+            if half and half_eligible(l):
+                cin = np.ascontiguousarray(inp.astype(np.float16).astype(np.float32))
+                cw = np.ascontiguousarray(l.weights.astype(np.float16).astype(np.float32))
+            L.orc_conv_forward_fused(fptr(cin), fptr(cw), fptr(l.biases),
                                      fptr(out), fptr(ws), None, B, l.c, l.h, l.w,
                                      l.n, l.groups, l.size, l.stride_x, l.stride_y,
                                      l.dilation, l.pad, l.activation)
