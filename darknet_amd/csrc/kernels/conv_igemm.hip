@@ -361,7 +361,8 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
     obase[j] = nv ? (unsigned)((b * p.Mtot + g * p.M) * p.OHW + pix) * 4u : 0xFFFFFFFFu;
   }
   const unsigned row_bytes = (unsigned)p.OHW * 4u;
-  auto emit = [&](auto check) {
+  // generic per-element path: edge tiles, exact mish / logistic / relu, pre-activation store
+  auto emit_generic = [&](auto check) {
     constexpr bool CHECK = decltype(check)::value;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -391,10 +392,83 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
       }
     }
   };
-  if (full_tile)
-    emit(std::false_type{});
+  // full tiles, the three activations the networks use: straight-line code.  The
+  // activation and the residual flag are launch constants, dispatched once.  Rows
+  // are handled four at a time (one 8-row group of the C/D layout): bias and
+  // residual values of the group are fetched first, so the loads overlap instead
+  // of being serialised behind the stores; the row part of every address is a
+  // scalar offset (soffset), the per-lane part is loop invariant.
+  auto emit_fast = [&](auto actc, auto resc) {
+    constexpr int ACT = decltype(actc)::value;
+    constexpr bool RES = decltype(resc)::value;
+    const int mlane = m0 + wm * WM + 4 * lh;
+    __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.bias ? p.bias + g * p.M : p.w), 0, p.bias ? (unsigned)p.M * 4u : 0u, 0x00020000);
+    unsigned vo[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) vo[j] = obase[j] + (unsigned)mlane * row_bytes;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+    {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+      {
+        float bv[4], res[4][TN];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          bv[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(br, mlane * 4, (i * 32 + 8 * q + t) * 4, 0));
+        if (RES)
+        {
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              res[t][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                  rr, (int)vo[j], (i * 32 + 8 * q + t) * (int)row_bytes, 0));
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+          {
+            float v = acc[i][j][4 * q + t] + bv[t];
+            if (ACT == DK_MISH)
+              v = dk_mish_fast(v);
+            else if (ACT == DK_LEAKY)
+              v = dk_leaky(v);
+            if (RES)
+              v += res[t][j];
+            __builtin_amdgcn_raw_buffer_store_b32(
+                __float_as_uint(v), yr, (int)vo[j], (i * 32 + 8 * q + t) * (int)row_bytes, 0);
+          }
+      }
+    }
+  };
+  using std::false_type;
+  using std::true_type;
+  using std::integral_constant;
+  if (full_tile && !has_ain)
+  {
+    if (act == (DK_MISH | DK_ACT_FAST))
+    {
+      if (has_res) emit_fast(integral_constant<int, DK_MISH>{}, true_type{});
+      else emit_fast(integral_constant<int, DK_MISH>{}, false_type{});
+    }
+    else if (act == DK_LEAKY)
+    {
+      if (has_res) emit_fast(integral_constant<int, DK_LEAKY>{}, true_type{});
+      else emit_fast(integral_constant<int, DK_LEAKY>{}, false_type{});
+    }
+    else if (act == DK_LINEAR)
+    {
+      if (has_res) emit_fast(integral_constant<int, DK_LINEAR>{}, true_type{});
+      else emit_fast(integral_constant<int, DK_LINEAR>{}, false_type{});
+    }
+    else
+      emit_generic(false_type{});
+  }
   else
-    emit(std::true_type{});
+    emit_generic(true_type{});
 }
 
 // --------------------------------------------------------------------------

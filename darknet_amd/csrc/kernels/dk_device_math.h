@@ -38,16 +38,16 @@ __device__ __forceinline__ float dk_mish(float x) { return x * dk_tanh(dk_softpl
 __device__ __forceinline__ float dk_leaky(float x) { return (x > 0.f) ? x : (float)(.1 * (double)x); }
 
 // Fast mish (conv epilogue default; DK_FAST_MISH=0 selects dk_mish; act bit 0x400): algebraically identical,
-// tanh(log(1+e)) = (e*e+2e)/(e*e+2e+2), one hardware exp and one division, no
-// cancellation.  Differs from the reference's own (cancellation-prone) formula
+// tanh(log(1+e)) = (e*e+2e)/(e*e+2e+2), one hardware exp and one hardware
+// reciprocal (1 ulp), no cancellation.  Differs from the reference's own (cancellation-prone) formula
 // by at most ~|x|*1.2e-7 absolute, the same size as glibc-vs-device libm noise.
 __device__ __forceinline__ float dk_mish_fast(float x)
 {
-  if (x > 20.f)
-    return x;
+  // branch-free: for x > 20 the quotient may be inf/inf, the select discards it
   const float e = __expf(x);
   const float w = e * (e + 2.f);
-  return x * __fdividef(w, w + 2.f);
+  const float r = x * (w * __builtin_amdgcn_rcpf(w + 2.f));
+  return (x > 20.f) ? x : r;
 }
 
 #define DK_ACT_FAST 0x400
