@@ -191,6 +191,8 @@ static void autotune_convs(Network* net)
         float best_ms = 1e30f;
         for (int c = 0; c < ncfg; ++c)
         {
+          if (!dk_conv_config_applicable(&hd, c))
+            continue;
           l->conv_cfg = c;
           l->forward_gpu(l, s);  // warm
           CHECK_HIP(hipEventRecord(e0, st));

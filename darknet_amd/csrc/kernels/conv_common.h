@@ -4,6 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
+#include "dk_device_math.h"
 #include "dk_kernels.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -56,6 +59,145 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 }
 
 constexpr unsigned OOB = 0x80000000u;  // ORed into a byte offset: always outside the buffer
+
+// --------------------------------------------------------------------------
+// Shared epilogue of the implicit-GEMM kernels: bias + activation (+ residual,
+// + pre-activation store) of the wave's TM x TN MFMA tiles, stored through
+// buffer descriptors.  C/D layout of the 32x32 MFMAs: col = lane&31,
+// row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Output (and residual / pre-activation)
+// are addressed with 32-bit byte offsets (the host keeps one launch's output < 4 GiB).
+// --------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[TM][TN], int m0,
+    int n0, int g, int wm, int wn, int l31, int lh)
+{
+  __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.y_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, p.residual ? p.y_bytes : 0u, 0x00020000);
+  __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc((void*)p.act_in, 0, p.act_in ? p.y_bytes : 0u, 0x00020000);
+  const bool has_res = p.residual != nullptr, has_ain = p.act_in != nullptr;
+  const int act = p.act;
+  const bool full_tile = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+  unsigned obase[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+  {
+    const int n = n0 + wn * WN + j * 32 + l31;
+    const bool nv = n < p.N;
+    const int nn = nv ? n : 0;
+    const int b = nn / p.OHW;
+    const int pix = nn - b * p.OHW;
+    obase[j] = nv ? (unsigned)((b * p.Mtot + g * p.M) * p.OHW + pix) * 4u : 0xFFFFFFFFu;
+  }
+  const unsigned row_bytes = (unsigned)p.OHW * 4u;
+  // generic per-element path: edge tiles, exact mish / logistic / relu, pre-activation store
+  auto emit_generic = [&](auto check) {
+    constexpr bool CHECK = decltype(check)::value;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+    {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+      {
+        const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (CHECK && m >= p.M)
+          continue;
+        const float bv = p.bias ? p.bias[g * p.M + m] : 0.f;
+        const unsigned mo = (unsigned)m * row_bytes;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+        {
+          if (CHECK && obase[j] == 0xFFFFFFFFu)
+            continue;
+          float v = acc[i][j][r] + bv;
+          const unsigned o = obase[j] + mo;
+          if (has_ain)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ar, (int)o, 0, 0);
+          v = dk_activate(v, act);
+          if (has_res)
+            v += ld_buf(rr, o);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yr, (int)o, 0, 0);
+        }
+      }
+    }
+  };
+  // full tiles, the three activations the networks use: straight-line code.  The
+  // activation and the residual flag are launch constants, dispatched once.  Rows
+  // are handled four at a time (one 8-row group of the C/D layout): bias and
+  // residual values of the group are fetched first, so the loads overlap instead
+  // of being serialised behind the stores; the row part of every address is a
+  // scalar offset (soffset), the per-lane part is loop invariant.
+  auto emit_fast = [&](auto actc, auto resc) {
+    constexpr int ACT = decltype(actc)::value;
+    constexpr bool RES = decltype(resc)::value;
+    const int mlane = m0 + wm * WM + 4 * lh;
+    __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.bias ? p.bias + g * p.M : p.w), 0, p.bias ? (unsigned)p.M * 4u : 0u, 0x00020000);
+    unsigned vo[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) vo[j] = obase[j] + (unsigned)mlane * row_bytes;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+    {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+      {
+        float bv[4], res[4][TN];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          bv[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(br, mlane * 4, (i * 32 + 8 * q + t) * 4, 0));
+        if (RES)
+        {
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              res[t][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                  rr, (int)vo[j], (i * 32 + 8 * q + t) * (int)row_bytes, 0));
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+          {
+            float v = acc[i][j][4 * q + t] + bv[t];
+            if (ACT == DK_MISH)
+              v = dk_mish_fast(v);
+            else if (ACT == DK_LEAKY)
+              v = dk_leaky(v);
+            if (RES)
+              v += res[t][j];
+            __builtin_amdgcn_raw_buffer_store_b32(
+                __float_as_uint(v), yr, (int)vo[j], (i * 32 + 8 * q + t) * (int)row_bytes, 0);
+          }
+      }
+    }
+  };
+  using std::false_type;
+  using std::true_type;
+  using std::integral_constant;
+  if (full_tile && !has_ain)
+  {
+    if (act == (DK_MISH | DK_ACT_FAST))
+    {
+      if (has_res) emit_fast(integral_constant<int, DK_MISH>{}, true_type{});
+      else emit_fast(integral_constant<int, DK_MISH>{}, false_type{});
+    }
+    else if (act == DK_LEAKY)
+    {
+      if (has_res) emit_fast(integral_constant<int, DK_LEAKY>{}, true_type{});
+      else emit_fast(integral_constant<int, DK_LEAKY>{}, false_type{});
+    }
+    else if (act == DK_LINEAR)
+    {
+      if (has_res) emit_fast(integral_constant<int, DK_LINEAR>{}, true_type{});
+      else emit_fast(integral_constant<int, DK_LINEAR>{}, false_type{});
+    }
+    else
+      emit_generic(false_type{});
+  }
+  else
+    emit_generic(true_type{});
+}
 
 
 // host side (conv_igemm.hip): per-shape tap table, created on first use

@@ -339,141 +339,20 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
     __syncthreads();
   }
 
-  // ---- epilogue -----------------------------------------------------------
-  // C/D layout of 32x32x2: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-  // Output (and residual / pre-activation) addressed with 32-bit byte offsets
-  // through buffer descriptors (the host keeps one launch's output < 4 GiB).
-  __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.y_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, p.residual ? p.y_bytes : 0u, 0x00020000);
-  __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc((void*)p.act_in, 0, p.act_in ? p.y_bytes : 0u, 0x00020000);
-  const bool has_res = p.residual != nullptr, has_ain = p.act_in != nullptr;
-  const int act = p.act;
-  const bool full_tile = (m0 + BM <= p.M) && (n0 + BN <= p.N);
-  unsigned obase[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j)
-  {
-    const int n = n0 + wn * WN + j * 32 + l31;
-    const bool nv = n < p.N;
-    const int nn = nv ? n : 0;
-    const int b = nn / p.OHW;
-    const int pix = nn - b * p.OHW;
-    obase[j] = nv ? (unsigned)((b * p.Mtot + g * p.M) * p.OHW + pix) * 4u : 0xFFFFFFFFu;
-  }
-  const unsigned row_bytes = (unsigned)p.OHW * 4u;
-  // generic per-element path: edge tiles, exact mish / logistic / relu, pre-activation store
-  auto emit_generic = [&](auto check) {
-    constexpr bool CHECK = decltype(check)::value;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-    {
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-      {
-        const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (CHECK && m >= p.M)
-          continue;
-        const float bv = p.bias ? p.bias[g * p.M + m] : 0.f;
-        const unsigned mo = (unsigned)m * row_bytes;
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-        {
-          if (CHECK && obase[j] == 0xFFFFFFFFu)
-            continue;
-          float v = acc[i][j][r] + bv;
-          const unsigned o = obase[j] + mo;
-          if (has_ain)
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ar, (int)o, 0, 0);
-          v = dk_activate(v, act);
-          if (has_res)
-            v += ld_buf(rr, o);
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yr, (int)o, 0, 0);
-        }
-      }
-    }
-  };
-  // full tiles, the three activations the networks use: straight-line code.  The
-  // activation and the residual flag are launch constants, dispatched once.  Rows
-  // are handled four at a time (one 8-row group of the C/D layout): bias and
-  // residual values of the group are fetched first, so the loads overlap instead
-  // of being serialised behind the stores; the row part of every address is a
-  // scalar offset (soffset), the per-lane part is loop invariant.
-  auto emit_fast = [&](auto actc, auto resc) {
-    constexpr int ACT = decltype(actc)::value;
-    constexpr bool RES = decltype(resc)::value;
-    const int mlane = m0 + wm * WM + 4 * lh;
-    __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.bias ? p.bias + g * p.M : p.w), 0, p.bias ? (unsigned)p.M * 4u : 0u, 0x00020000);
-    unsigned vo[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) vo[j] = obase[j] + (unsigned)mlane * row_bytes;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-    {
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-      {
-        float bv[4], res[4][TN];
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-          bv[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(br, mlane * 4, (i * 32 + 8 * q + t) * 4, 0));
-        if (RES)
-        {
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-              res[t][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                  rr, (int)vo[j], (i * 32 + 8 * q + t) * (int)row_bytes, 0));
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-          {
-            float v = acc[i][j][4 * q + t] + bv[t];
-            if (ACT == DK_MISH)
-              v = dk_mish_fast(v);
-            else if (ACT == DK_LEAKY)
-              v = dk_leaky(v);
-            if (RES)
-              v += res[t][j];
-            __builtin_amdgcn_raw_buffer_store_b32(
-                __float_as_uint(v), yr, (int)vo[j], (i * 32 + 8 * q + t) * (int)row_bytes, 0);
-          }
-      }
-    }
-  };
-  using std::false_type;
-  using std::true_type;
-  using std::integral_constant;
-  if (full_tile && !has_ain)
-  {
-    if (act == (DK_MISH | DK_ACT_FAST))
-    {
-      if (has_res) emit_fast(integral_constant<int, DK_MISH>{}, true_type{});
-      else emit_fast(integral_constant<int, DK_MISH>{}, false_type{});
-    }
-    else if (act == DK_LEAKY)
-    {
-      if (has_res) emit_fast(integral_constant<int, DK_LEAKY>{}, true_type{});
-      else emit_fast(integral_constant<int, DK_LEAKY>{}, false_type{});
-    }
-    else if (act == DK_LINEAR)
-    {
-      if (has_res) emit_fast(integral_constant<int, DK_LINEAR>{}, true_type{});
-      else emit_fast(integral_constant<int, DK_LINEAR>{}, false_type{});
-    }
-    else
-      emit_generic(false_type{});
-  }
-  else
-    emit_generic(true_type{});
+  conv_epilogue<BM, BN, WM, WN, TM, TN>(p, acc, m0, n0, g, wm, wn, l31, lh);
 }
 
 // --------------------------------------------------------------------------
 // host side: plans (tap table + tile choice), dispatch, profiling
 // --------------------------------------------------------------------------
+// conv3x3_direct.hip: the patch-in-LDS kernel for 3x3/s1/p1 layers; its tile
+// configurations are numbered after the gather configurations.
+int dk_conv_direct_num_configs();
+const char* dk_conv_direct_config_name(int dcfg);
+const char* dk_conv_direct_kernel_name(int dcfg, int pitch_class);
+bool dk_conv_direct_applicable(const DkConvDesc* d, const float* weights, int dcfg);
+int dk_conv_direct_launch(ConvArgs a, int dcfg, hipStream_t st);
+
 namespace
 {
 struct TileCfg
@@ -547,16 +426,31 @@ bool fast_mish()
 
 int out_dim(int in, int pad, int size, int stride) { return (in + 2 * pad - size) / stride + 1; }
 
-int pick_cfg(int M, long long N, int groups)
+int env_cfg()
 {
-  if (g_forced >= 0 && g_forced < g_ncfg)
-    return g_forced;
   static int env = -2;
   if (env == -2)
   {
     const char* e = getenv("DK_CONV_CFG");
     env = e ? atoi(e) : -1;
   }
+  return env;
+}
+
+// heuristic: 3x3/s1/p1 layers take the patch-in-LDS kernel, 64x128 tiles when they
+// fill the chip at least twice, else 64x64 (measured on yolov4's layers); -1 = gather
+int pick_direct(const DkConvDesc* d, const float* weights, int M, long long N)
+{
+  const long long t128 = (long long)((M + 63) / 64) * ((N + 127) / 128);
+  const int dc = t128 >= 512 ? 2 : 3;
+  return dk_conv_direct_applicable(d, weights, dc) ? g_ncfg + dc : -1;
+}
+
+int pick_cfg(int M, long long N, int groups)
+{
+  if (g_forced >= 0 && g_forced < g_ncfg)
+    return g_forced;
+  const int env = env_cfg();
   if (env >= 0 && env < g_ncfg)
     return env;
   const int CUS = 256;
@@ -633,12 +527,23 @@ Plan& get_plan(const DkConvDesc* d, int K, int C, int mode = 0)
 extern "C" int dk_conv_force_config(int cfg)
 {
   g_forced = cfg;
-  return g_ncfg;
+  return g_ncfg + dk_conv_direct_num_configs();
 }
 
 extern "C" const char* dk_conv_config_name(int cfg)
 {
+  if (cfg >= g_ncfg)
+    return dk_conv_direct_config_name(cfg - g_ncfg);
   return (cfg >= 0 && cfg < g_ncfg) ? g_cfgs[cfg].name : nullptr;
+}
+
+bool dk_conv_config_applicable(const DkConvDesc* d, int cfg)
+{
+  if (cfg < 0)
+    return false;
+  if (cfg < g_ncfg)
+    return true;
+  return dk_conv_direct_applicable(d, nullptr, cfg - g_ncfg);
 }
 
 extern "C" int dk_conv_pick_config(const DkConvDesc* d)
@@ -646,6 +551,12 @@ extern "C" int dk_conv_pick_config(const DkConvDesc* d)
   const int pad = d->pad * d->dilation;
   const int eff = d->dilation * (d->size - 1) + 1;
   const int oh = out_dim(d->h, pad, eff, d->stride_y), ow = out_dim(d->w, pad, eff, d->stride_x);
+  if (g_forced < 0 && env_cfg() < 0)
+  {
+    const int dc = pick_direct(d, nullptr, d->n / d->groups, (long long)d->batch * oh * ow);
+    if (dc >= 0)
+      return dc;
+  }
   return pick_cfg(d->n / d->groups, (long long)d->batch * oh * ow, d->groups);
 }
 
@@ -683,14 +594,17 @@ extern "C" int dk_profile_read(double* out, int max_cfgs)
     (void)hipEventDestroy(r.e1);
   }
   g_prof.clear();
-  return g_ncfg * 4;
+  return (g_ncfg + dk_conv_direct_num_configs()) * 4;
 }
 
-// Kernel symbol exactly as rocprofv3 prints it, for profile slot idx = cfg*4 + AVEC + 2*BVEC.
+// Kernel symbol exactly as rocprofv3 prints it, for profile slot idx = cfg*4 + AVEC + 2*BVEC
+// (direct 3x3 configurations: cfg*4 + pitch class).
 extern "C" __attribute__((visibility("default"))) const char* dk_conv_kernel_name(int idx)
 {
   static char buf[128];
-  if (idx < 0 || idx >= g_ncfg * 4)
+  if (idx >= g_ncfg * 4)
+    return dk_conv_direct_kernel_name(idx / 4 - g_ncfg, idx & 3);
+  if (idx < 0)
     return nullptr;
   const TileCfg& c = g_cfgs[idx / 4];
   snprintf(buf, sizeof(buf), "conv_igemm_f32<%d, %d, %d, %d, %d, %s, %s>", c.bm, c.bn, c.bk, c.wm,
@@ -698,7 +612,7 @@ extern "C" __attribute__((visibility("default"))) const char* dk_conv_kernel_nam
   return buf;
 }
 
-int dk_conv_num_configs() { return g_ncfg; }
+int dk_conv_num_configs() { return g_ncfg + dk_conv_direct_num_configs(); }
 
 const int2* dk_conv_ktab(const DkConvDesc* d, int K, int C, int mode) { return get_plan(d, K, C, mode).ktab; }
 
@@ -793,6 +707,32 @@ int dk_conv_forward_cfg(const DkConvDesc* d, const float* x, const float* weight
     a.act = d->activation;
     if (d->activation == DK_MISH && fast_mish())
       a.act |= DK_ACT_FAST;
+    int want = cfg_override >= 0 ? cfg_override : (g_forced >= 0 ? g_forced : env_cfg());
+    const int ntot = g_ncfg + dk_conv_direct_num_configs();
+    if (want < 0)
+      want = pick_direct(d, weights, M, a.N);
+    if (want >= g_ncfg && want < ntot && dk_conv_direct_applicable(d, weights, want - g_ncfg))
+    {
+      ProfRec pr;
+      if (g_prof_on)
+      {
+        CHECK_HIP(hipEventCreate(&pr.e0));
+        CHECK_HIP(hipEventCreate(&pr.e1));
+        CHECK_HIP(hipEventRecord(pr.e0, st));
+      }
+      a.groups = 1;
+      a.mode = 0;
+      const int pc = dk_conv_direct_launch(a, want - g_ncfg, st);
+      CHECK_HIP(hipPeekAtLastError());
+      if (g_prof_on)
+      {
+        CHECK_HIP(hipEventRecord(pr.e1, st));
+        pr.cfg = want * 4 + pc;
+        pr.gflop = 2.0 * (double)M * K * (double)a.N / 1e9;
+        g_prof.push_back(pr);
+      }
+      continue;
+    }
     const int ci = (cfg_override >= 0 && cfg_override < g_ncfg) ? cfg_override : pick_cfg(M, a.N, d->groups);
     const TileCfg& c = g_cfgs[ci];
     a.tiles_m = (M + c.bm - 1) / c.bm;

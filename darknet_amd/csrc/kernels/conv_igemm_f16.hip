@@ -188,51 +188,8 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
     __syncthreads();
   }
 
-  // ---- epilogue (fp32), identical to the fp32 kernel's
-  __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.y_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, p.residual ? p.y_bytes : 0u, 0x00020000);
-  __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc((void*)p.act_in, 0, p.act_in ? p.y_bytes : 0u, 0x00020000);
-  const bool has_res = p.residual != nullptr, has_ain = p.act_in != nullptr;
-  const int act = p.act;
-  unsigned obase[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j)
-  {
-    const int n = n0 + wn * WN + j * 32 + l31;
-    const bool nv = n < p.N;
-    const int nn = nv ? n : 0;
-    const int b = nn / p.OHW;
-    const int pix = nn - b * p.OHW;
-    obase[j] = nv ? (unsigned)((b * p.Mtot + g * p.M) * p.OHW + pix) * 4u : 0xFFFFFFFFu;
-  }
-  const unsigned row_bytes = (unsigned)p.OHW * 4u;
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-  {
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-    {
-      const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (m >= p.M)
-        continue;
-      const float bv = p.bias ? p.bias[g * p.M + m] : 0.f;
-      const unsigned mo = (unsigned)m * row_bytes;
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-      {
-        if (obase[j] == 0xFFFFFFFFu)
-          continue;
-        float v = acc[i][j][r] + bv;
-        const unsigned o = obase[j] + mo;
-        if (has_ain)
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ar, (int)o, 0, 0);
-        v = dk_activate(v, act);
-        if (has_res)
-          v += ld_buf(rr, o);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yr, (int)o, 0, 0);
-      }
-    }
-  }
+  // ---- epilogue (fp32), shared with the fp32 kernel
+  conv_epilogue<BM, BN, WM, WN, TM, TN>(p, acc, m0, n0, g, wm, wn, l31, lh);
 }
 
 // Eligibility rule of the reference's fp16 path (src/convolutional_kernels.cu:361-365);

@@ -9,3 +9,6 @@ int dk_conv_forward_cfg(const DkConvDesc* d, const float* x, const float* weight
 // Makes sure the per-shape tap table exists (must happen outside stream capture).
 void dk_conv_prepare(const DkConvDesc* d);
 int dk_conv_num_configs();
+// true when tile configuration `cfg` can run this layer (the direct 3x3 configurations,
+// indices >= the number of gather configurations, only take 3x3/s1/p1 layers)
+bool dk_conv_config_applicable(const DkConvDesc* d, int cfg);

@@ -67,6 +67,43 @@ def test_conv_forward_vs_oracle(gpu, case):
     gpu.lib().dk_conv_force_config(-1)
 
 
+DIRECT_CASES = [
+    # batch, c, h, w, n, act : 3x3 / stride 1 / pad 1 layers for the patch-in-LDS kernel
+    (3, 8, 19, 19, 64, "MISH"),       # pitch 24; 361-pixel images: tiles straddle images
+    (2, 12, 30, 22, 32, "LEAKY"),     # pitch 24, non-square
+    (2, 8, 38, 38, 40, "MISH"),       # pitch 40, ragged M
+    (1, 8, 76, 76, 130, "LEAKY"),     # pitch 80, ragged M > one tile
+    (1, 4, 152, 152, 32, "LINEAR"),   # pitch 160
+    (2, 16, 64, 64, 64, "MISH"),      # pitch 80, W a power of two
+    (1, 4, 26, 26, 16, "LEAKY"),      # pitch 40, N = 676 (ragged last tile)
+]
+
+
+@pytest.mark.parametrize("case", DIRECT_CASES)
+def test_conv_direct3x3_vs_oracle(gpu, case):
+    """Every tile configuration (gather and direct) on 3x3/s1/p1 layers, with bias, the fused
+    activation and a residual (the straight-line epilogue), against the CPU oracle."""
+    batch, c, h, w, n, actname = case
+    act = getattr(O, actname)
+    rng = np.random.default_rng(hash(case) & 0xFFFF)
+    x = rng.uniform(-1, 1, (batch, c, h, w)).astype(np.float32)
+    wt = (rng.uniform(-1, 1, (n, c, 3, 3)) * np.sqrt(2.0 / (9 * c))).astype(np.float32)
+    bias = rng.uniform(-.5, .5, n).astype(np.float32)
+    res = rng.uniform(-1, 1, (batch, n, h, w)).astype(np.float32)
+    ref, _ = orc_conv(x, wt, bias, batch, c, h, w, n, 3, 1, 1, act)
+    L = gpu.lib()
+    ncfg = L.dk_conv_force_config(-1)
+    names = [L.dk_conv_config_name(i).decode() for i in range(ncfg)]
+    assert any(nm.startswith("direct3x3") for nm in names)
+    for cfg in range(ncfg):
+        L.dk_conv_force_config(cfg)
+        y = gpu.conv_forward(x, wt, bias, batch, c, h, w, n, 3, 1, 1, act)
+        util.assert_close(y, ref, "conv %s %s" % (names[cfg], case))
+        y = gpu.conv_forward(x, wt, bias, batch, c, h, w, n, 3, 1, 1, act, residual=res)
+        util.assert_close(y, ref + res, "conv + residual %s %s" % (names[cfg], case))
+    L.dk_conv_force_config(-1)
+
+
 def test_conv_identity_asymmetric(gpu):
     """A = I check with an asymmetric B: catches a transposed C/D fragment map."""
     c = n = 64

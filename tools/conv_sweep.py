@@ -55,8 +55,11 @@ def main():
             L.dk_profile_read(out, 64)
             L.dk_profile_enable(0)
             ms = sum(out[(cfgi * 4 + v) * 3 + 2] for v in range(4)) / iters
-            gf = sum(out[(cfgi * 4 + v) * 3 + 1] for v in range(4)) / iters
-            times.append(ms)
+            g1 = sum(out[(cfgi * 4 + v) * 3 + 1] for v in range(4)) / iters
+            if g1 > 0:
+                gf = g1
+            # a direct-3x3 configuration that cannot take this layer falls back: not a candidate
+            times.append(ms if ms > 0 else float("inf"))
         best = int(np.argmin(times))
         cnt = len(idxs)
         tot_best += times[best] * cnt
