@@ -56,6 +56,8 @@ void FillUpsampleLayer(layer* l, int batch, int w, int h, int c, int stride);
 void FillYoloLayer(layer* l, int batch, int w, int h, int n, int total, int* mask, int classes,
     int max_boxes);
 
+// the buffer readers of layer l's output use (a single-input [route] may alias its source)
+inline float* DkLayerOut(const layer* l) { return l->out_alias ? l->out_alias : l->output_gpu; }
 bool dk_gpu_enabled();  // true when a HIP device is usable (cuda_get_device() >= 0)
 
 // graph-level options (network.cpp)

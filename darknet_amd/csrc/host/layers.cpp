@@ -202,18 +202,24 @@ void ForwardConvolutionalLayerGpu(layer* l, NetworkState state)
     // shortcut layer's buffer (the next layer).
     layer* sc = &state.net->layers[l->index + 1];
     out = sc->output_gpu;
-    residual = state.net->layers[l->fuse_residual_from].output_gpu;
+    residual = DkLayerOut(&state.net->layers[l->fuse_residual_from]);
   }
   float* act_in = (state.train && l->activation_input_gpu) ? l->activation_input_gpu : nullptr;
+  int out_ctot = 0;
+  if (l->out_view && !state.train)
+  {
+    out = l->out_view;  // channel slice of the consuming route's buffer
+    out_ctot = l->out_view_ctot;
+  }
   if (state.net->cudnn_half && !state.train && dk_conv_half_eligible(&d, l->index))
   {
-    if (dk_conv_forward_half(&d, state.input, l->weights_gpu, l->biases_gpu, out, residual, act_in,
-            get_cuda_stream()))
+    if (dk_conv_forward_half_strided(&d, state.input, l->weights_gpu, l->biases_gpu, out, residual,
+            act_in, get_cuda_stream(), out_ctot))
       error("ForwardConvolutionalLayerGpu (fp16 operands) failed");
     return;
   }
   if (dk_conv_forward_cfg(&d, state.input, l->weights_gpu, l->biases_gpu, out, residual, act_in,
-          get_cuda_stream(), l->conv_cfg))
+          get_cuda_stream(), l->conv_cfg, out_ctot))
     error("ForwardConvolutionalLayerGpu failed");
 }
 
@@ -304,8 +310,15 @@ void FillMaxpoolLayer(layer* l, int batch, int h, int w, int c, int size, int st
 
 void ForwardMaxpoolLayerGpu(layer* l, NetworkState state)
 {
-  if (dk_maxpool_forward(state.input, l->output_gpu, l->indexes_gpu, l->batch, l->c, l->h, l->w,
-          l->size, l->stride_x, l->stride_y, l->pad, get_cuda_stream()))
+  float* out = l->output_gpu;
+  size_t bstride = 0;
+  if (l->out_view && !state.train)
+  {
+    out = l->out_view;
+    bstride = (size_t)l->out_view_ctot * l->out_h * l->out_w;
+  }
+  if (dk_maxpool_forward_strided(state.input, out, state.train ? l->indexes_gpu : nullptr, l->batch,
+          l->c, l->h, l->w, l->size, l->stride_x, l->stride_y, l->pad, bstride, get_cuda_stream()))
     error("ForwardMaxpoolLayerGpu failed");
 }
 
@@ -339,13 +352,20 @@ void FillRouteLayer(layer* l, int batch, int n, int* input_layers, int* input_si
 
 void ForwardRouteLayerGpu(layer* l, NetworkState state)
 {
+  if (l->out_alias && !state.train)
+    return;  // single input: readers use the source's buffer (DkLayerOut)
   int offset = 0;
   for (int i = 0; i < l->n; ++i)
   {
     const int index = l->input_layers[i];
-    const float* input = state.net->layers[index].output_gpu;
+    const float* input = DkLayerOut(&state.net->layers[index]);
     const int input_size = l->input_sizes[i];
     const int part = input_size / l->groups;
+    if (l->input_inplace && l->input_inplace[i] && !state.train)
+    {
+      offset += part;  // the producer wrote this slice itself
+      continue;
+    }
     if (dk_route_copy(input, input_size, l->groups, l->group_id, l->batch, l->output_gpu,
             l->outputs, offset, get_cuda_stream()))
       error("ForwardRouteLayerGpu failed");
@@ -403,7 +423,7 @@ void ForwardShortcutLayerGpu(layer* l, NetworkState state)
   if (l->activation != LINEAR && l->activation != LEAKY && l->activation != LOGISTIC &&
       l->activation != RELU && l->activation != MISH)
     error("ForwardShortcutLayerGpu: unsupported activation");
-  if (dk_shortcut_forward(state.input, from->output_gpu, l->output_gpu,
+  if (dk_shortcut_forward(state.input, DkLayerOut(from), l->output_gpu,
           (size_t)l->outputs * l->batch, (int)l->activation, get_cuda_stream()))
     error("ForwardShortcutLayerGpu failed");
 }
@@ -436,8 +456,15 @@ void FillUpsampleLayer(layer* l, int batch, int w, int h, int c, int stride)
 
 void ForwardUpsampleLayerGpu(layer* l, NetworkState state)
 {
-  if (dk_upsample_forward(state.input, l->w, l->h, l->c, l->batch, l->stride, l->scale,
-          l->output_gpu, get_cuda_stream()))
+  float* out = l->output_gpu;
+  size_t bstride = 0;
+  if (l->out_view && !state.train)
+  {
+    out = l->out_view;
+    bstride = (size_t)l->out_view_ctot * l->out_h * l->out_w;
+  }
+  if (dk_upsample_forward_strided(state.input, l->w, l->h, l->c, l->batch, l->stride, l->scale, out,
+          bstride, get_cuda_stream()))
     error("ForwardUpsampleLayerGpu failed");
 }
 
@@ -576,7 +603,7 @@ void free_layer(layer* l, bool)
     free(l->output);
   l->output = nullptr;
   free(l->mask); free(l->cost); free(l->indexes);
-  free(l->input_layers); free(l->input_sizes);
+  free(l->input_layers); free(l->input_sizes); free(l->input_inplace);
   free(l->biases); free(l->bias_updates); free(l->scales); free(l->scale_updates);
   free(l->weights); free(l->weight_updates);
   free(l->delta);

@@ -13,6 +13,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
+#include <vector>
 #include <chrono>
 
 #include "dk_host.h"
@@ -137,7 +139,7 @@ static void run_layers_eager(Network* net, NetworkState state)
     if (l->forward_gpu)
       l->forward_gpu(l, state);
     if (l->output_gpu)
-      state.input = l->output_gpu;
+      state.input = DkLayerOut(l);
   }
 }
 
@@ -213,7 +215,7 @@ static void autotune_convs(Network* net)
       }
     }
     if (l->output_gpu)
-      in = l->output_gpu;
+      in = DkLayerOut(l);
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
@@ -245,6 +247,70 @@ void DkPlanInference(Network* net)
       continue;
     cv->fuse_residual_from = sc->index;
     sc->fused_into_prev = 1;
+  }
+  // 1b. zero-copy concatenation: a producer read by nobody but one multi-input [route]
+  // writes its channel slice of the route's buffer itself; a one-input [route] aliases
+  // its source.  (route_layer.c:124-142 copies every input; here most copies vanish.)
+  for (int i = 0; i < net->n; ++i)
+  {
+    layer* l = &net->layers[i];
+    l->out_view = nullptr;
+    l->out_view_ctot = 0;
+    l->out_alias = nullptr;
+    free(l->input_inplace);
+    l->input_inplace = nullptr;
+  }
+  if (g_dk_fusion)
+  {
+    std::vector<int> readers(net->n, 0);
+    for (int i = 0; i < net->n; ++i)
+    {
+      layer* l = &net->layers[i];
+      if (l->type == ROUTE)
+        for (int k = 0; k < l->n; ++k) readers[l->input_layers[k]]++;
+      else
+      {
+        if (i > 0)
+          readers[i - 1]++;  // every other layer kind reads its predecessor
+        if (l->type == SHORTCUT)
+          readers[l->index]++;
+      }
+    }
+    readers[net->n - 1]++;  // the network's output
+    for (int i = 0; i < net->n; ++i)
+    {
+      layer* r = &net->layers[i];
+      if (r->type != ROUTE || r->groups != 1)
+        continue;
+      if (r->n == 1)
+        continue;
+      r->input_inplace = (int*)xcalloc(r->n, sizeof(int));
+      size_t offset = 0;
+      for (int k = 0; k < r->n; ++k)
+      {
+        layer* pl = &net->layers[r->input_layers[k]];
+        const bool kind_ok = (pl->type == CONVOLUTIONAL && !pl->batch_normalize && pl->fuse_residual_from < 0) ||
+                             pl->type == MAXPOOL || pl->type == UPSAMPLE;
+        const size_t hw = (size_t)pl->out_h * pl->out_w;
+        if (kind_ok && readers[r->input_layers[k]] == 1 && !pl->out_view && hw > 0 &&
+            (size_t)r->outputs % hw == 0 && pl->outputs == r->input_sizes[k])
+        {
+          pl->out_view = r->output_gpu + offset;
+          pl->out_view_ctot = (int)((size_t)r->outputs / hw);
+          r->input_inplace[k] = 1;
+        }
+        offset += r->input_sizes[k];
+      }
+    }
+    for (int i = 0; i < net->n; ++i)
+    {
+      layer* r = &net->layers[i];
+      if (r->type != ROUTE || r->groups != 1 || r->n != 1)
+        continue;
+      layer* src = &net->layers[r->input_layers[0]];
+      if (!src->out_view && src->outputs == r->outputs)
+        r->out_alias = DkLayerOut(src);
+    }
   }
   // 2. tap tables (must exist before any stream capture)
   for (int i = 0; i < net->n; ++i)
@@ -325,7 +391,7 @@ void ForwardNetworkGpu(Network* net, NetworkState state)
     if (net->wait_stream)
       CHECK_HIP(hipStreamSynchronize(st));
     if (l->output_gpu)
-      state.input = l->output_gpu;
+      state.input = DkLayerOut(l);
   }
 }
 
@@ -620,7 +686,16 @@ int DkLayerOutput(Network* net, int i, float* dst, size_t n)
   if (!l->output_gpu || n < total)
     return 1;
   NetworkSync(net);
-  cuda_pull_array(l->output_gpu, dst, total);
+  if (l->out_view)
+  {
+    // written in place as a channel slice of the consuming route's buffer
+    const size_t hw = (size_t)l->out_h * l->out_w;
+    CHECK_HIP(hipMemcpy2D(dst, (size_t)l->outputs * sizeof(float), l->out_view,
+        (size_t)l->out_view_ctot * hw * sizeof(float), (size_t)l->outputs * sizeof(float), l->batch,
+        hipMemcpyDeviceToHost));
+    return 0;
+  }
+  cuda_pull_array(DkLayerOut(l), dst, total);
   return 0;
 }
 

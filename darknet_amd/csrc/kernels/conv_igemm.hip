@@ -630,7 +630,7 @@ extern "C" int dk_conv_forward(const DkConvDesc* d, const float* x, const float*
 
 int dk_conv_forward_cfg(const DkConvDesc* d, const float* x, const float* weights,
     const float* biases, float* y, const float* residual, float* activation_input, void* stream,
-    int cfg_override)
+    int cfg_override, int out_ctot)
 {
   if (!d || !x || !weights || !y || d->groups < 1 || d->c % d->groups || d->n % d->groups ||
       d->size < 1 || d->stride_x < 1 || d->stride_y < 1 || d->dilation < 1)
@@ -664,7 +664,13 @@ int dk_conv_forward_cfg(const DkConvDesc* d, const float* x, const float* weight
   }
   const int C = d->c / d->groups, M = d->n / d->groups, K = C * d->size * d->size;
   const size_t in_img = (size_t)d->c * d->h * d->w;
-  const size_t out_img = (size_t)d->n * OH * OW;
+  if (out_ctot && (out_ctot < d->n || residual || activation_input))
+  {
+    fprintf(stderr, "dk_conv_forward: a channel-slice output takes no residual / pre-activation\n");
+    return 1;
+  }
+  const int Mtot = out_ctot ? out_ctot : d->n;
+  const size_t out_img = (size_t)Mtot * OH * OW;  // batch stride of the output
   // the gather uses 32-bit byte offsets checked by the buffer descriptor:
   // process the batch in chunks whose input stays below 2 GiB
   const size_t max_elems = (size_t)1 << 29;  // byte offsets stay below 2^31: bit 31 is the "masked" flag
@@ -697,9 +703,9 @@ int dk_conv_forward_cfg(const DkConvDesc* d, const float* x, const float* weight
     a.ktab = pl.ktab;
     a.x_bytes = (unsigned)(in_img * nb * sizeof(float));
     a.w_bytes = (unsigned)((size_t)M * K * sizeof(float));
-    a.y_bytes = (unsigned)(out_img * nb * sizeof(float));
+    a.y_bytes = (unsigned)((out_img * (nb - 1) + (size_t)d->n * OH * OW) * sizeof(float));
     a.C = C; a.H = d->h; a.W = d->w; a.Ctot = d->c;
-    a.M = M; a.Mtot = d->n; a.K = K;
+    a.M = M; a.Mtot = Mtot; a.K = K;
     a.OH = OH; a.OW = OW; a.OHW = OH * OW;
     a.N = nb * OH * OW;
     a.size = d->size; a.stride_x = d->stride_x; a.stride_y = d->stride_y;

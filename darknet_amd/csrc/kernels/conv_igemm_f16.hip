@@ -203,6 +203,13 @@ extern "C" int dk_conv_half_eligible(const DkConvDesc* d, int layer_index)
 extern "C" int dk_conv_forward_half(const DkConvDesc* d, const float* x, const float* weights,
     const float* biases, float* y, const float* residual, float* activation_input, void* stream)
 {
+  return dk_conv_forward_half_strided(d, x, weights, biases, y, residual, activation_input, stream, 0);
+}
+
+int dk_conv_forward_half_strided(const DkConvDesc* d, const float* x, const float* weights,
+    const float* biases, float* y, const float* residual, float* activation_input, void* stream,
+    int out_ctot)
+{
   if (!d || !x || !weights || !y || !dk_conv_half_eligible(d, 1))
   {
     fprintf(stderr, "dk_conv_forward_half: layer is not eligible for the fp16-operand path\n");
@@ -213,7 +220,10 @@ extern "C" int dk_conv_forward_half(const DkConvDesc* d, const float* x, const f
   const int OH = (d->h + 2 * pad - keff) / d->stride_y + 1;
   const int OW = (d->w + 2 * pad - keff) / d->stride_x + 1;
   const int C = d->c, M = d->n, K = C * d->size * d->size;
-  const size_t in_img = (size_t)d->c * d->h * d->w, out_img = (size_t)d->n * OH * OW;
+  if (out_ctot && (out_ctot < d->n || residual || activation_input))
+    return 1;
+  const int Mtot = out_ctot ? out_ctot : d->n;
+  const size_t in_img = (size_t)d->c * d->h * d->w, out_img = (size_t)Mtot * OH * OW;
   int chunk = d->batch;
   const size_t lim_in = (size_t)1 << 29, lim_out = (size_t)1 << 30;
   if (in_img * chunk >= lim_in || out_img * chunk >= lim_out)
@@ -247,9 +257,9 @@ extern "C" int dk_conv_forward_half(const DkConvDesc* d, const float* x, const f
     a.ktab = ktab;
     a.x_bytes = (unsigned)(in_img * nb * 4);
     a.w_bytes = (unsigned)((size_t)M * K * 4);
-    a.y_bytes = (unsigned)(out_img * nb * 4);
+    a.y_bytes = (unsigned)((out_img * (nb - 1) + (size_t)d->n * OH * OW) * 4);
     a.C = C; a.H = d->h; a.W = d->w; a.Ctot = d->c;
-    a.M = M; a.Mtot = d->n; a.K = K;
+    a.M = M; a.Mtot = Mtot; a.K = K;
     a.OH = OH; a.OW = OW; a.OHW = OH * OW;
     a.N = nb * OH * OW;
     a.size = d->size; a.stride_x = d->stride_x; a.stride_y = d->stride_y;

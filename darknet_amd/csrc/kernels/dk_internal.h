@@ -2,10 +2,23 @@
 #pragma once
 #include "dk_kernels.h"
 
+#include <stddef.h>
+
 // dk_conv_forward with an explicit tile configuration (cfg < 0: heuristic).
+// out_ctot > 0: `y` is a channel slice of a wider tensor with out_ctot channels
+// (zero-copy concatenation: batch stride = out_ctot*oh*ow); no residual then.
 int dk_conv_forward_cfg(const DkConvDesc* d, const float* x, const float* weights,
     const float* biases, float* y, const float* residual, float* activation_input, void* stream,
-    int cfg);
+    int cfg, int out_ctot = 0);
+int dk_conv_forward_half_strided(const DkConvDesc* d, const float* x, const float* weights,
+    const float* biases, float* y, const float* residual, float* activation_input, void* stream,
+    int out_ctot);
+// maxpool / upsample writing a channel slice of a wider tensor (out_batch_stride floats
+// between batch items; 0 = dense)
+int dk_maxpool_forward_strided(const float* x, float* y, int* indexes, int batch, int c, int h,
+    int w, int size, int stride_x, int stride_y, int pad, size_t out_batch_stride, void* stream);
+int dk_upsample_forward_strided(const float* in, int w, int h, int c, int batch, int stride,
+    float scale, float* out, size_t out_batch_stride, void* stream);
 // Makes sure the per-shape tap table exists (must happen outside stream capture).
 void dk_conv_prepare(const DkConvDesc* d);
 int dk_conv_num_configs();

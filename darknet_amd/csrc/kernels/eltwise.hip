@@ -8,6 +8,7 @@
 
 #include "dark_hip.h"
 #include "dk_kernels.h"
+#include "dk_internal.h"
 #include "dk_device_math.h"
 
 namespace
@@ -65,7 +66,7 @@ __global__ void shortcut_kernel(const float* __restrict__ a, const float* __rest
 
 // one thread per OUTPUT element pair: out row = 2 floats per input float for stride 2
 __global__ void upsample_kernel(const float* __restrict__ in, float* __restrict__ out, int w, int h,
-    size_t planes, int stride, float scale)
+    size_t planes, int stride, float scale, int c, size_t out_bstride)
 {
   const int ow = w * stride, oh = h * stride;
   const size_t total = planes * (size_t)oh * ow;
@@ -76,7 +77,9 @@ __global__ void upsample_kernel(const float* __restrict__ in, float* __restrict_
     const size_t t = i / ow;
     const int oy = (int)(t % oh);
     const size_t pl = t / oh;
-    out[i] = scale * in[(pl * h + oy / stride) * w + ox / stride];
+    const size_t b = pl / c;
+    out[b * out_bstride + ((pl - b * c) * oh + oy) * (size_t)ow + ox] =
+        scale * in[(pl * h + oy / stride) * w + ox / stride];
   }
 }
 
@@ -178,6 +181,12 @@ extern "C" int dk_shortcut_forward(const float* in, const float* from, float* ou
 extern "C" int dk_upsample_forward(const float* in, int w, int h, int c, int batch, int stride,
     float scale, float* out, void* stream)
 {
+  return dk_upsample_forward_strided(in, w, h, c, batch, stride, scale, out, 0, stream);
+}
+
+int dk_upsample_forward_strided(const float* in, int w, int h, int c, int batch, int stride,
+    float scale, float* out, size_t out_batch_stride, void* stream)
+{
   if (!in || !out || stride < 1)
   {
     fprintf(stderr, "dk_upsample_forward: invalid arguments\n");
@@ -188,7 +197,8 @@ extern "C" int dk_upsample_forward(const float* in, int w, int h, int c, int bat
   if (total == 0)
     return 0;
   hipLaunchKernelGGL(upsample_kernel, dim3(grid_for(total)), dim3(256), 0, S(stream), in, out, w,
-      h, planes, stride, scale);
+      h, planes, stride, scale, c,
+      out_batch_stride ? out_batch_stride : (size_t)c * h * w * stride * stride);
   CHECK_HIP(hipPeekAtLastError());
   return 0;
 }

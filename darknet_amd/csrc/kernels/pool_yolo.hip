@@ -6,6 +6,7 @@
 #include "dark_hip.h"
 #include "dk_kernels.h"
 #include "dk_device_math.h"
+#include "dk_internal.h"
 
 namespace
 {
@@ -24,7 +25,7 @@ inline int grid_for(size_t work, int threads = 256)
 // strict '>' (first maximum wins), index = flat input index.
 __global__ void maxpool_kernel(const float* __restrict__ x, float* __restrict__ y,
     int* __restrict__ indexes, size_t total, int c, int h, int w, int out_h, int out_w, int size,
-    int stride_x, int stride_y, int pad)
+    int stride_x, int stride_y, int pad, size_t out_bstride)
 {
   const int w_off = -pad / 2, h_off = -pad / 2;
   for (size_t id = blockIdx.x * (size_t)blockDim.x + threadIdx.x; id < total;
@@ -56,9 +57,74 @@ __global__ void maxpool_kernel(const float* __restrict__ x, float* __restrict__ 
         }
       }
     }
-    y[id] = max;
+    const size_t bi = plane / c;
+    y[bi * out_bstride + (plane - bi * c) * (size_t)out_h * out_w + (size_t)i * out_w + j] = max;
     if (indexes)
       indexes[id] = max_i;
+  }
+}
+
+// Stride-1 pools on small planes (the SPP block: 5/9/13 windows on 19x19): one block
+// per (b, c) plane held in LDS, separable scan.  Row pass: per (row, ox) the window
+// maximum and its FIRST column (strict '>'); column pass: strict '>' over the rows ->
+// the first row holding the maximum and that row's first column, i.e. exactly the
+// element the reference's row-major window scan keeps (value and index identical).
+__global__ void __launch_bounds__(256) maxpool_plane_kernel(const float* __restrict__ x,
+    float* __restrict__ y, int* __restrict__ indexes, int c, int h, int w, int out_h, int out_w,
+    int size, int pad, size_t out_bstride)
+{
+  extern __shared__ float sm[];
+  float* plane_s = sm;                     // [h][w]
+  float* rmax = sm + h * w;                // [h][out_w]
+  int* ridx = (int*)(rmax + h * out_w);    // [h][out_w] column of the row maximum (-1: empty window)
+  const size_t plane = blockIdx.x;
+  const float* src = x + plane * (size_t)h * w;
+  for (int i = threadIdx.x; i < h * w; i += blockDim.x) plane_s[i] = src[i];
+  __syncthreads();
+  const int off = -pad / 2;
+  for (int i = threadIdx.x; i < h * out_w; i += blockDim.x)
+  {
+    const int r = i / out_w, j = i - r * out_w;
+    float max = -FLT_MAX;
+    int mi = -1;
+    for (int m = 0; m < size; ++m)
+    {
+      const int cw = off + j + m;
+      if ((unsigned)cw >= (unsigned)w)
+        continue;
+      const float v = plane_s[r * w + cw];
+      if (v > max)
+      {
+        max = v;
+        mi = cw;
+      }
+    }
+    rmax[i] = max;
+    ridx[i] = mi;
+  }
+  __syncthreads();
+  const size_t bi = plane / c;
+  float* dst = y + bi * out_bstride + (plane - bi * c) * (size_t)out_h * out_w;
+  for (int i = threadIdx.x; i < out_h * out_w; i += blockDim.x)
+  {
+    const int oy = i / out_w, j = i - oy * out_w;
+    float max = -FLT_MAX;
+    int max_i = -1;
+    for (int n = 0; n < size; ++n)
+    {
+      const int ch = off + oy + n;
+      if ((unsigned)ch >= (unsigned)h)
+        continue;
+      const float v = rmax[ch * out_w + j];
+      if (v > max)
+      {
+        max = v;
+        max_i = (int)(plane * h * w) + ch * w + ridx[ch * out_w + j];
+      }
+    }
+    dst[i] = max;
+    if (indexes)
+      indexes[plane * (size_t)out_h * out_w + i] = max_i;
   }
 }
 
@@ -87,6 +153,12 @@ __global__ void yolo_decode_kernel(const float* __restrict__ in, float* __restri
 extern "C" int dk_maxpool_forward(const float* x, float* y, int* indexes, int batch, int c, int h,
     int w, int size, int stride_x, int stride_y, int pad, void* stream)
 {
+  return dk_maxpool_forward_strided(x, y, indexes, batch, c, h, w, size, stride_x, stride_y, pad, 0, stream);
+}
+
+int dk_maxpool_forward_strided(const float* x, float* y, int* indexes, int batch, int c, int h,
+    int w, int size, int stride_x, int stride_y, int pad, size_t out_batch_stride, void* stream)
+{
   if (!x || !y || size < 1 || stride_x < 1 || stride_y < 1)
   {
     fprintf(stderr, "dk_maxpool_forward: invalid arguments\n");
@@ -102,8 +174,17 @@ extern "C" int dk_maxpool_forward(const float* x, float* y, int* indexes, int ba
     fprintf(stderr, "dk_maxpool_forward: input too large for int indexes\n");
     return 1;
   }
+  const size_t obs = out_batch_stride ? out_batch_stride : (size_t)c * out_h * out_w;
+  const size_t lds = ((size_t)h * w + 2 * (size_t)h * out_w) * sizeof(float);
+  if (stride_x == 1 && stride_y == 1 && size >= 3 && lds <= 48 * 1024)
+  {
+    hipLaunchKernelGGL(maxpool_plane_kernel, dim3((unsigned)(batch * c)), dim3(256), lds, S(stream), x, y,
+        indexes, c, h, w, out_h, out_w, size, pad, obs);
+    CHECK_HIP(hipPeekAtLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total)), dim3(256), 0, S(stream), x, y, indexes,
-      total, c, h, w, out_h, out_w, size, stride_x, stride_y, pad);
+      total, c, h, w, out_h, out_w, size, stride_x, stride_y, pad, obs);
   CHECK_HIP(hipPeekAtLastError());
   return 0;
 }

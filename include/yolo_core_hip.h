@@ -196,6 +196,12 @@ struct layer
   int fused_into_prev;   /* shortcut folded into the previous conv's epilogue */
   int fuse_residual_from; /* conv: layer index whose output is added in the epilogue, or -1 */
   int conv_cfg;          /* tile configuration chosen by the autotuner, or -1 */
+  /* zero-copy concatenation (inference plan): a producer whose only reader is a multi-input
+   * [route] writes straight into that route's buffer; a single-input [route] is an alias */
+  float* out_view;       /* producer: where the output really goes (a channel slice), or NULL */
+  int out_view_ctot;     /* producer: channels of the tensor out_view is a slice of */
+  float* out_alias;      /* route with one input: the source's buffer, or NULL */
+  int* input_inplace;    /* route: per input, 1 = the producer already wrote it in place */
   float* injected_delta; /* yolo (tests): host delta used instead of the loss, see DkSetYoloDelta */
 };
 
