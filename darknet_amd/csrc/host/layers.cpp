@@ -185,6 +185,7 @@ void DkConvPrepare(layer* l)
 // handled in train.cpp (raw GEMM, then batch statistics, then activation).
 void ForwardConvTrainGpu(layer* l, NetworkState state);  // train.cpp
 void DkYoloTrainDelta(layer* l, NetworkState state);      // train.cpp
+void DkFreeLossTask(layer* l);                            // train.cpp
 
 void ForwardConvolutionalLayerGpu(layer* l, NetworkState state)
 {
@@ -606,7 +607,11 @@ void free_layer(layer* l, bool)
   free(l->input_layers); free(l->input_sizes); free(l->input_inplace);
   free(l->biases); free(l->bias_updates); free(l->scales); free(l->scale_updates);
   free(l->weights); free(l->weight_updates);
-  free(l->delta);
+  DkFreeLossTask(l);
+  if (l->delta_pinned && l->delta)
+    cuda_free_host(l->delta);
+  else
+    free(l->delta);
   free(l->activation_input);
   free(l->mean); free(l->variance); free(l->mean_delta); free(l->variance_delta);
   free(l->rolling_mean); free(l->rolling_variance);

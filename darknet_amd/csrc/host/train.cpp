@@ -9,6 +9,8 @@
 // BN eps / rolling momentum / N-1 variance as on the CPU; the data gradient
 // OVERWRITES the previous layer's delta; for BN layers bias_updates is the true
 // sum of delta (the CPU reference leaves it 0 -- quirk 3).
+#include <chrono>
+#include <future>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -146,8 +148,11 @@ void BackwardUpsampleLayerGpu(layer* l, NetworkState state)
       get_cuda_stream());
 }
 
+static void DkYoloLossJoin(layer* l);
+
 void BackwardYoloLayerGpu(layer* l, NetworkState state)
 {
+  DkYoloLossJoin(l);
   // axpy_ongpu(batch*inputs, loss_scale, delta_gpu, state.delta), yolo_layer.cpp:884-888
   dk_axpy((size_t)l->batch * l->inputs, state.net->loss_scale, l->delta_gpu, state.delta,
       get_cuda_stream());
@@ -165,9 +170,60 @@ void DkSetMaxIter(Network* net, int max_iter) { net->max_iter = max_iter; }
 extern "C" float DkYoloLossHost(const layer* l, int net_w, int net_h, float* out,
     const float* truth, float* delta);
 
-// called by ForwardYoloLayerGpu in train mode (layers.cpp): the loss lives on the
-// host, as in the reference (src/yolo_layer.cpp:861-881): pull the decoded output,
-// compute delta and cost, push the delta.
+// The yolo loss lives on the host, as in the reference (src/yolo_layer.cpp:861-881:
+// pull the decoded output, compute delta and cost, push the delta).  The reference
+// does this synchronously inside the forward pass; here the head is copied out on
+// the copy stream and the loss runs on host threads WHILE the GPU computes the
+// remaining layers; the delta is pushed when the backward pass reaches the layer
+// (DkYoloLossJoin).  Same values, no GPU idle time.
+static bool train_timing()
+{
+  static int v = -1;
+  if (v < 0)
+  {
+    const char* e = getenv("DK_TRAIN_TIMING");
+    v = (e && atoi(e)) ? 1 : 0;
+  }
+  return v == 1;
+}
+static double now_ms()
+{
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct LossTask
+{
+  std::future<float> fut;
+  hipEvent_t decoded = nullptr, copied = nullptr;
+  bool running = false;
+};
+
+static LossTask* loss_task_of(layer* l)
+{
+  if (!l->loss_task)
+  {
+    LossTask* t = new LossTask();
+    CHECK_HIP(hipEventCreateWithFlags(&t->decoded, hipEventDisableTiming));
+    CHECK_HIP(hipEventCreateWithFlags(&t->copied, hipEventDisableTiming));
+    l->loss_task = t;
+  }
+  return (LossTask*)l->loss_task;
+}
+
+void DkFreeLossTask(layer* l)
+{
+  LossTask* t = (LossTask*)l->loss_task;
+  if (!t)
+    return;
+  if (t->running)
+    t->fut.wait();
+  (void)hipEventDestroy(t->decoded);
+  (void)hipEventDestroy(t->copied);
+  delete t;
+  l->loss_task = nullptr;
+}
+
+// called by ForwardYoloLayerGpu in train mode (layers.cpp), after the decode kernel
 void DkYoloTrainDelta(layer* l, NetworkState state)
 {
   const size_t total = (size_t)l->batch * l->outputs;
@@ -178,11 +234,41 @@ void DkYoloTrainDelta(layer* l, NetworkState state)
   }
   if (!state.net->truth)
     error("yolo loss: no truth supplied (TrainNetworkDatum(net, x, y) with y != NULL)");
-  cuda_pull_array(l->output_gpu, l->output, total);  // synchronises the stream
   if (!l->delta)
-    l->delta = (float*)xcalloc(total, sizeof(float));
-  *(l->cost) = DkYoloLossHost(l, state.net->w, state.net->h, l->output, state.net->truth, l->delta);
-  cuda_push_array(l->delta_gpu, l->delta, total);
+  {
+    l->delta = cuda_make_array_pinned(nullptr, total);
+    l->delta_pinned = 1;
+  }
+  LossTask* t = loss_task_of(l);
+  if (t->running)
+    t->fut.wait();
+  hipStream_t st = get_cuda_stream(), cs = get_cuda_memcpy_stream();
+  CHECK_HIP(hipEventRecord(t->decoded, st));
+  CHECK_HIP(hipStreamWaitEvent(cs, t->decoded, 0));
+  CHECK_HIP(hipMemcpyAsync(l->output, l->output_gpu, total * sizeof(float), hipMemcpyDeviceToHost, cs));
+  CHECK_HIP(hipEventRecord(t->copied, cs));
+  const int dev = cuda_get_device();
+  const int net_w = state.net->w, net_h = state.net->h;
+  const float* truth = state.net->truth;
+  hipEvent_t copied = t->copied;
+  t->fut = std::async(std::launch::async, [l, dev, net_w, net_h, truth, copied]() {
+    (void)hipSetDevice(dev);
+    CHECK_HIP(hipEventSynchronize(copied));
+    return DkYoloLossHost(l, net_w, net_h, l->output, truth, l->delta);
+  });
+  t->running = true;
+}
+
+// waits for the layer's host loss, stores the cost, enqueues the delta upload
+static void DkYoloLossJoin(layer* l)
+{
+  LossTask* t = (LossTask*)l->loss_task;
+  if (!t || !t->running)
+    return;
+  *(l->cost) = t->fut.get();
+  t->running = false;
+  CHECK_HIP(hipMemcpyAsync(l->delta_gpu, l->delta, (size_t)l->batch * l->outputs * sizeof(float),
+      hipMemcpyHostToDevice, get_cuda_stream()));
 }
 
 void BackwardNetworkGpu(Network* net, NetworkState state)
@@ -247,20 +333,33 @@ void ForwardBackwardNetworkGpu(Network* net, float* x, float* y)
   memset(&state, 0, sizeof(state));
   state.net = net;
   const size_t x_size = (size_t)GetNetworkInputSize(net) * net->batch;
+  const double t0 = now_ms();
   memcpy(net->input_pinned_cpu, x, x_size * sizeof(float));
   cuda_push_array(net->input_state_gpu, net->input_pinned_cpu, x_size);
   state.input = net->input_state_gpu;
   state.delta = 0;
   state.truth = 0;
   state.train = 1;
+  const double t1 = now_ms();
   ForwardNetworkGpu(net, state);
+  const double t2 = now_ms();
   BackwardNetworkGpu(net, state);
+  if (train_timing())
+  {
+    const double t3 = now_ms();
+    CHECK_HIP(hipStreamSynchronize(get_cuda_stream()));
+    fprintf(stderr, "[train timing] input %.2f ms, forward issue %.2f, backward issue (+ loss joins) %.2f, drain %.2f\n",
+        t1 - t0, t2 - t1, t3 - t2, now_ms() - t3);
+  }
 }
 
 float TrainNetworkDatumGpu(Network* net, float* x, float* y)
 {
   net->seen += net->batch;
   ForwardBackwardNetworkGpu(net, x, y);
+  for (int i = 0; i < net->n; ++i)
+    if (net->layers[i].type == YOLO)
+      DkYoloLossJoin(&net->layers[i]);  // layers the backward pass did not reach
   CHECK_HIP(hipStreamSynchronize(get_cuda_stream()));
   // GetNetworkCost (network.cpp:145-158): mean of the layers' cost[0]
   float sum = 0;

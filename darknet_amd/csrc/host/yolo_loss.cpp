@@ -12,6 +12,11 @@
 // golden vectors dumped from the real reference (tests/golden/yololoss_*.npz).
 #include <float.h>
 #include <math.h>
+#include <algorithm>
+#include <atomic>
+#include <thread>
+#include <utility>
+#include <vector>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -319,20 +324,27 @@ inline int entry(const layer* l, int b, int location, int e)
 // [batch][outputs] (NaN/Inf objectness is zeroed in place, as the reference does),
 // `truth` = [batch][max_boxes*5], `delta` (zero-filled here) receives the loss
 // gradient; returns *(l->cost).
-extern "C" LIB_API float DkYoloLossHost(const layer* l, int net_w, int net_h, float* out,
-    const float* truth, float* delta)
+namespace
+{
+struct ImageLoss
+{
+  std::vector<std::pair<float, float>> iou_terms;  // (1 - iou, 1 - giou) in the order the reference adds them
+  std::vector<std::vector<int>> positives;          // per anchor: cells whose class/box deltas were written
+};
+
+// passes 1-3 of the train branch for ONE image (images are independent)
+void yolo_loss_image(const layer* l, int net_w, int net_h, float* out, const float* truth,
+    float* delta, int b, ImageLoss* res)
 {
   const int stride = l->w * l->h;
-  memset(delta, 0, (size_t)l->outputs * l->batch * sizeof(float));
-  float tot_iou_loss = 0, tot_giou_loss = 0, avg_cat = 0;
-  int count = 0;
-  auto truth_box = [&](int b, int t) {
-    const float* f = truth + t * (4 + 1) + b * l->truths;
+  memset(delta + (size_t)b * l->outputs, 0, (size_t)l->outputs * sizeof(float));
+  res->positives.assign(l->n, std::vector<int>());
+  float avg_cat = 0;
+  auto truth_box = [&](int bb, int t) {
+    const float* f = truth + t * (4 + 1) + bb * l->truths;
     return Box(f[0], f[1], f[2], f[3]);
   };
-  auto truth_class = [&](int b, int t) { return (int)truth[t * (4 + 1) + b * l->truths + 4]; };
-
-  for (int b = 0; b < l->batch; ++b)
+  auto truth_class = [&](int bb, int t) { return (int)truth[t * (4 + 1) + bb * l->truths + 4]; };
   {
     // ---- pass 1: every predictor -> no-object delta unless it overlaps a truth well
     for (int j = 0; j < l->h; ++j)
@@ -347,6 +359,7 @@ extern "C" LIB_API float DkYoloLossHost(const layer* l, int net_w, int net_h, fl
               net_h, stride);
           float best_match_iou = 0, best_iou = 0;
           int best_t = 0;
+          int class_match = -1;  // evaluated once per cell (the reference re-evaluates it per truth)
           for (int t = 0; t < l->max_boxes; ++t)
           {
             const Box tb = truth_box(b, t);
@@ -363,13 +376,16 @@ extern "C" LIB_API float DkYoloLossHost(const layer* l, int net_w, int net_h, fl
             if (isnan(objectness) || isinf(objectness))
               out[obj_index] = 0;
             // compare_yolo_class: does ANY class probability exceed 0.25?
-            int class_match = 0;
-            for (int c = 0; c < l->classes; ++c)
-              if (out[class_index + stride * c] > 0.25f)
-              {
-                class_match = 1;
-                break;
-              }
+            if (class_match < 0)
+            {
+              class_match = 0;
+              for (int c = 0; c < l->classes; ++c)
+                if (out[class_index + stride * c] > 0.25f)
+                {
+                  class_match = 1;
+                  break;
+                }
+            }
             const float iou = Box::Iou(pred, tb);
             if (iou > best_match_iou && class_match == 1)
               best_match_iou = iou;
@@ -394,6 +410,7 @@ extern "C" LIB_API float DkYoloLossHost(const layer* l, int net_w, int net_h, fl
             const float mult = l->classes_multipliers ? l->classes_multipliers[class_id] : 1.0f;
             box_delta(tb, out, l->biases, l->mask[n], box_index, i, j, l->w, l->h, net_w, net_h,
                 delta, (2 - tb.w * tb.h), stride, l->iou_normalizer * mult, l->iou_loss, l->max_delta);
+            res->positives[n].push_back(j * l->w + i);
           }
         }
 
@@ -436,14 +453,13 @@ extern "C" LIB_API float DkYoloLossHost(const layer* l, int net_w, int net_h, fl
         const IouPair ious = box_delta(tb, out, l->biases, anchor, box_index, i, j, l->w, l->h,
             net_w, net_h, delta, (2 - tb.w * tb.h), stride, l->iou_normalizer * mult, l->iou_loss,
             l->max_delta);
-        tot_iou_loss += 1 - ious.iou;
-        tot_giou_loss += 1 - ious.giou;
+        res->iou_terms.emplace_back(1 - ious.iou, 1 - ious.giou);
         const int obj_index = entry(l, b, loc, 4);
         delta[obj_index] = mult * l->cls_normalizer * (1 - out[obj_index]);
         const int class_index = entry(l, b, loc, 4 + 1);
         class_delta(out, delta, class_index, class_id, l->classes, stride, &avg_cat, l->focal_loss,
             l->label_smooth_eps, l->classes_multipliers);
-        ++count;
+        res->positives[mask_n].push_back(j * l->w + i);
       };
       auto mask_index = [&](int anchor) {
         for (int k = 0; k < l->n; ++k)
@@ -468,46 +484,104 @@ extern "C" LIB_API float DkYoloLossHost(const layer* l, int net_w, int net_h, fl
       }
     }
 
-    // ---- pass 3: a box shared by several positive classes gets its delta averaged
-    for (int j = 0; j < l->h; ++j)
-      for (int i = 0; i < l->w; ++i)
-        for (int n = 0; n < l->n; ++n)
-        {
-          const int loc = n * stride + j * l->w + i;
-          const int box_index = entry(l, b, loc, 0), class_index = entry(l, b, loc, 4 + 1);
-          int positives = 0;
-          for (int c = 0; c < l->classes; ++c)
-            if (delta[class_index + stride * c] > 0)
-              positives++;
-          if (positives > 0)
-            for (int e = 0; e < 4; ++e) delta[box_index + e * stride] /= positives;
-        }
+    // ---- pass 3: a box shared by several positive classes gets its delta averaged.
+    // Class deltas are non-zero only at the cells recorded above (everything else
+    // was zero-filled and never written), so only those cells can have positives.
+    for (int n = 0; n < l->n; ++n)
+    {
+      std::vector<int>& cells = res->positives[n];
+      std::sort(cells.begin(), cells.end());
+      cells.erase(std::unique(cells.begin(), cells.end()), cells.end());
+      for (int cell : cells)
+      {
+        const int loc = n * stride + cell;
+        const int box_index = entry(l, b, loc, 0), class_index = entry(l, b, loc, 4 + 1);
+        int positives = 0;
+        for (int c = 0; c < l->classes; ++c)
+          if (delta[class_index + stride * c] > 0)
+            positives++;
+        if (positives > 0)
+          for (int e = 0; e < 4; ++e) delta[box_index + e * stride] /= positives;
+      }
+    }
   }
+}
+}  // namespace
+
+// The train branch of ForwardYoloLayer on host arrays: `out` = decoded yolo output
+// [batch][outputs] (NaN/Inf objectness is zeroed in place, as the reference does),
+// `truth` = [batch][max_boxes*5], `delta` (zero-filled here) receives the loss
+// gradient; returns *(l->cost).  Images are processed by parallel threads (they are
+// independent); every floating-point accumulation that crosses images or cells is
+// then replayed in the reference's order, so deltas AND cost are bit-identical to the
+// sequential reference (tests/test_yolo_loss_cpu.py).
+extern "C" LIB_API float DkYoloLossHost(const layer* l, int net_w, int net_h, float* out,
+    const float* truth, float* delta)
+{
+  const int stride = l->w * l->h;
+  std::vector<ImageLoss> img(l->batch);
+  {
+    unsigned hw = std::thread::hardware_concurrency();
+    int nthreads = (int)(hw ? hw : 1);
+    if (const char* e = getenv("DK_LOSS_THREADS"))
+      nthreads = atoi(e);
+    if (nthreads > l->batch) nthreads = l->batch;
+    if (nthreads > 16) nthreads = 16;
+    if (nthreads <= 1)
+      for (int b = 0; b < l->batch; ++b) yolo_loss_image(l, net_w, net_h, out, truth, delta, b, &img[b]);
+    else
+    {
+      std::atomic<int> next(0);
+      std::vector<std::thread> pool;
+      for (int t = 0; t < nthreads; ++t)
+        pool.emplace_back([&]() {
+          for (int b = next++; b < l->batch; b = next++)
+            yolo_loss_image(l, net_w, net_h, out, truth, delta, b, &img[b]);
+        });
+      for (auto& th : pool) th.join();
+    }
+  }
+  float tot_iou_loss = 0, tot_giou_loss = 0;
+  int count = 0;
+  for (int b = 0; b < l->batch; ++b)
+    for (const auto& t : img[b].iou_terms)
+    {
+      tot_iou_loss += t.first;
+      tot_giou_loss += t.second;
+      ++count;
+    }
   if (count == 0)
     count = 1;
 
-  // cost: iou part (mean 1-IoU or 1-GIoU) + cls_normalizer * |delta without the box terms|^2
-  const int total = l->outputs * l->batch;
-  float* no_box = (float*)xcalloc(total, sizeof(float));
-  memcpy(no_box, delta, (size_t)total * sizeof(float));
-  for (int b = 0; b < l->batch; ++b)
-    for (int loc = 0; loc < l->n * stride; ++loc)
-      for (int e = 0; e < 4; ++e) no_box[entry(l, b, loc, e)] = 0;
-  float m;
-  {
+  // cost: iou part (mean 1-IoU or 1-GIoU) + cls_normalizer * |delta without the box terms|^2.
+  // The reference sums delta[i]^2 over the whole array in index order (mag_array); the
+  // structurally zero entries (class/box deltas of cells never marked positive) add
+  // exactly 0, so only the objectness planes and the positive cells are visited --
+  // in the same index order, hence the same float result.
+  auto sum_squares = [&](bool with_box) {
     float sum = 0;
-    for (int i = 0; i < total; ++i) sum += no_box[i] * no_box[i];
-    m = sqrtf(sum);
-  }
+    for (int b = 0; b < l->batch; ++b)
+      for (int n = 0; n < l->n; ++n)
+      {
+        const std::vector<int>& cells = img[b].positives[n];
+        for (int e = 0; e < 4 + 1 + l->classes; ++e)
+        {
+          const float* plane = delta + entry(l, b, n * stride, e);
+          if (e < 4 && !with_box)
+            continue;
+          if (e == 4)
+            for (int i = 0; i < stride; ++i) sum += plane[i] * plane[i];
+          else
+            for (int cell : cells) sum += plane[cell] * plane[cell];
+        }
+      }
+    return sum;
+  };
+  const float m = sqrtf(sum_squares(false));
   const float classification_loss = l->cls_normalizer * pow(m, 2);
-  free(no_box);
   float cost;
   if (l->iou_loss == MSE)
-  {
-    float sum = 0;
-    for (int i = 0; i < total; ++i) sum += delta[i] * delta[i];
-    cost = pow(sqrtf(sum), 2);
-  }
+    cost = pow(sqrtf(sum_squares(true)), 2);
   else
   {
     const float avg_iou_loss = (l->iou_loss == GIOU) ? l->iou_normalizer * (tot_giou_loss / count)

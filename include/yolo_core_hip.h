@@ -203,6 +203,7 @@ struct layer
   float* out_alias;      /* route with one input: the source's buffer, or NULL */
   int* input_inplace;    /* route: per input, 1 = the producer already wrote it in place */
   float* injected_delta; /* yolo (tests): host delta used instead of the loss, see DkSetYoloDelta */
+  void* loss_task;       /* yolo (train): host loss of the current step, running beside the GPU */
 };
 
 struct Network
