@@ -83,6 +83,19 @@ void BackwardConvolutionalLayerGpu(layer* l, NetworkState state)
   {
     const int Cg = l->c / l->groups, Mg = l->n / l->groups;
     float* wt = state.net->wt_scratch_gpu;
+    if (l->size == 3 && l->stride_x == 1 && l->stride_y == 1 && l->pad == 1 && l->dilation == 1 &&
+        l->groups == 1)
+    {
+      // stride-1 "same" 3x3: the data gradient IS a 3x3/s1/p1 convolution of delta with
+      // the transposed, 180-degree-rotated filters -> the forward kernels (patch-in-LDS
+      // where it applies).  Overwrites prev_delta like the gather path.
+      dk_transpose_weights_flip(l->weights_gpu, wt, Mg, Cg, 3, st);
+      DkConvDesc dd = d;
+      dd.c = l->n; dd.h = l->out_h; dd.w = l->out_w; dd.n = l->c;
+      if (dk_conv_forward_cfg(&dd, l->delta_gpu, wt, nullptr, state.delta, nullptr, nullptr, st, -1))
+        error("data gradient (as convolution) failed");
+      return;
+    }
     for (int g = 0; g < l->groups; ++g)
       dk_transpose_weights(l->weights_gpu + (size_t)g * l->nweights / l->groups,
           wt + (size_t)g * l->nweights / l->groups, Mg, Cg, l->size, st);

@@ -275,7 +275,13 @@ struct PitchClass
 {
   int p, rows;
 };
-const PitchClass g_pc[4] = {{24, 12}, {40, 10}, {80, 7}, {160, 6}};
+// (row pitch, rows): sized for the feature maps of 416/512/608 nets with 64..128-pixel tiles
+// (w = 13..22 | 23..38 | 39..78 | 79..158)
+#define DK_PC0 24, 15
+#define DK_PC1 40, 10
+#define DK_PC2 80, 8
+#define DK_PC3 160, 6
+const PitchClass g_pc[4] = {{DK_PC0}, {DK_PC1}, {DK_PC2}, {DK_PC3}};
 
 struct DirectCfg
 {
@@ -288,8 +294,8 @@ struct DirectCfg
   {                                                                                            \
     BM, BN, WM, WN, "direct3x3_" #BM "x" #BN "_w" #WM "x" #WN,                                 \
     {                                                                                          \
-      conv3x3_direct_f32<BM, BN, WM, WN, 24, 12>, conv3x3_direct_f32<BM, BN, WM, WN, 40, 10>,  \
-          conv3x3_direct_f32<BM, BN, WM, WN, 80, 7>, conv3x3_direct_f32<BM, BN, WM, WN, 160, 6> \
+      conv3x3_direct_f32<BM, BN, WM, WN, DK_PC0>, conv3x3_direct_f32<BM, BN, WM, WN, DK_PC1>,  \
+          conv3x3_direct_f32<BM, BN, WM, WN, DK_PC2>, conv3x3_direct_f32<BM, BN, WM, WN, DK_PC3> \
     }                                                                                          \
   }
 

@@ -6,11 +6,16 @@
 //     dW[m][k] += sum_n delta[m][n] * col[k][n]      n = (image, oy, ox), k = (c,kh,kw)
 // The contraction runs over n, which is huge (batch*oh*ow) while the output is
 // small (n x k*k*c), so the n range is split over many workgroups, each
-// accumulates a 64x64 tile of dW in MFMA accumulators over its slice and adds it
+// accumulates a tile of dW in MFMA accumulators over its slice and adds it
 // to dW with float atomics (dW accumulates across images and subdivisions in
 // the reference anyway: beta = 1).  col is gathered on the fly (no im2col
-// buffer): a thread owns 4 fixed taps k and walks the pixels.
-// Round-1 kernel: correctness first (64x64 tile, 16 pixels per step).
+// buffer): a thread owns a few fixed taps k and walks the pixels.
+// Kernel: block tile (64*TM) x (64*TK) of dW, 4 waves in a 2x2 arrangement (each
+// 32*TM x 32*TK), 32 pixels per stage, double-buffered LDS with one barrier per
+// stage, the next stage's global loads in flight during the MFMAs.  delta rows are
+// read with float4 loads when the image size allows; col taps use the forward
+// kernel's branch-free gather (per-stage padding mask of the thread's pixel,
+// out-of-range flag ORed into the byte offset, hardware bounds check).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -19,6 +24,7 @@
 #include "dk_kernels.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace
 {
@@ -34,21 +40,26 @@ struct WgradArgs
   int OH, OW, OHW;
   int N;               // batch*OHW
   int size, stride_x, stride_y, pad, dil;
-  int tiles_m, tiles_k, nsplit, chunks_per_split, groups;
+  int tiles_m, tiles_k, nsplit, stages_per_split, groups;
 };
 
 constexpr unsigned OOB = 0x80000000u;
-constexpr int BM = 64, BKO = 64, NC = 16, LS = NC + 1, T = 256;
+constexpr int NC = 32, LS = NC + 1, T = 256;
 
 __device__ __forceinline__ float ld_buf(__amdgpu_buffer_rsrc_t r, unsigned byte_off)
 {
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
 }
 
+template <int TM, int TK, bool AVEC>
 __global__ void __launch_bounds__(T) conv_wgrad_f32(const WgradArgs p)
 {
-  __shared__ float As[BM * LS];   // delta tile  [m][n]
-  __shared__ float Bs[BKO * LS];  // col tile    [k][n]
+  constexpr int BM = 64 * TM, BKO = 64 * TK;
+  constexpr int A_FL = BM * LS, B_FL = BKO * LS, STAGE = A_FL + B_FL;
+  constexpr int PA = AVEC ? BM / 32 : BM / 8;   // delta loads per thread and stage
+  constexpr int PB = BKO / 8;                   // gather loads per thread and stage
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // 2 stages: [m][n] delta, [k][n] col
+
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wk = wave & 1;
   const int l31 = lane & 31, lh = lane >> 5;
@@ -66,86 +77,210 @@ __global__ void __launch_bounds__(T) conv_wgrad_f32(const WgradArgs p)
   __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc((void*)p.delta, 0, p.d_bytes, 0x00020000);
 
-  const int nl = tid % NC;   // pixel within the chunk
-  const int r0 = tid / NC;   // row 0..15 (+16j)
-  // fixed taps of this thread
-  int tap_c[4], tap_dy[4], tap_dx[4];
-  bool tap_ok[4];
+  const int nstages = (p.N + NC - 1) / NC;
+  int st_begin = split * p.stages_per_split;
+  int st_end = st_begin + p.stages_per_split;
+  if (st_end > nstages)
+    st_end = nstages;
+
+  // ---- the thread's fixed taps (B rows) -------------------------------------------
+  const int nl = tid & 31;      // pixel within the stage
+  const int r8 = tid >> 5;      // 0..7
   const int ss = p.size * p.size;
+  unsigned toff[PB];            // byte offset of the tap inside an image-group, or OOB
+  int tsh[PB];                  // 31 - tap: shifts the tap's "outside" bit to the sign position
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < PB; ++j)
   {
-    const int k = k0 + r0 + 16 * j;
-    tap_ok[j] = k < p.K;
-    const int kk = tap_ok[j] ? k : 0;
+    const int k = k0 + r8 + 8 * j;
+    const bool ok = k < p.K;
+    const int kk = ok ? k : 0;
     const int c = kk / ss, t = kk - c * ss, kh = t / p.size, kw = t - kh * p.size;
-    tap_c[j] = c;
-    tap_dy[j] = kh * p.dil - p.pad;
-    tap_dx[j] = kw * p.dil - p.pad;
+    toff[j] = ok ? (unsigned)(c * HW + kh * p.dil * p.W + kw * p.dil) * 4u : OOB;
+    tsh[j] = 31 - t;
   }
-  bool row_ok[4];
+  // ---- the thread's fixed delta rows (A rows) ----------------------------------------
+  const int aq = AVEC ? (tid & 7) : nl;            // float4 index / pixel index inside the stage
+  const int ar = AVEC ? (tid >> 3) : r8;           // first row
+  constexpr int AR_STEP = AVEC ? 32 : 8;
+  unsigned roff[PA];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) row_ok[j] = (m0 + r0 + 16 * j) < p.M;
-
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-
-  const int nchunks = (p.N + NC - 1) / NC;
-  int ch_begin = split * p.chunks_per_split;
-  int ch_end = ch_begin + p.chunks_per_split;
-  if (ch_end > nchunks)
-    ch_end = nchunks;
-
-  for (int ch = ch_begin; ch < ch_end; ++ch)
+  for (int j = 0; j < PA; ++j)
   {
-    const int n = ch * NC + nl;
-    const bool nv = n < p.N;
-    const int nn = nv ? n : 0;
-    const int b = nn / p.OHW;
-    const int pix = nn - b * p.OHW;
-    const int oy = pix / p.OW, ox = pix - oy * p.OW;
-    float ra[4], rb[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
+    const int m = m0 + ar + AR_STEP * j;
+    roff[j] = (m < p.M) ? (unsigned)((g * p.M + m) * p.OHW) * 4u : OOB;
+  }
+
+  // ---- pixel state, advanced by NC per stage ------------------------------------------
+  // B (and scalar A): pixel n = st*NC + nl -> (b, pix, oy, ox); vector A: n = st*NC + 4*aq -> (bA, pixA)
+  int n = st_begin * NC + nl;
+  int b = n / p.OHW, pix = n - b * p.OHW;
+  int oy = pix / p.OW, ox = pix - oy * p.OW;
+  int nA = st_begin * NC + 4 * aq;
+  int bA = nA / p.OHW, pixA = nA - bA * p.OHW;
+
+  float ra[AVEC ? PA * 4 : PA], rb[PB];
+
+  auto load_stage = [&]() {
+    // delta
+    if (AVEC)
     {
-      const int m = m0 + r0 + 16 * j;
-      const unsigned off = (unsigned)((b * p.Mtot + g * p.M + m) * p.OHW + pix) * 4u;
-      ra[j] = ld_buf(dr, (nv && row_ok[j]) ? off : OOB);
-      const int iy = oy * p.stride_y + tap_dy[j], ix = ox * p.stride_x + tap_dx[j];
-      const bool ok = nv && tap_ok[j] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      const unsigned xo = (unsigned)((b * p.Ctot + g * p.C + tap_c[j]) * HW + iy * p.W + ix) * 4u;
-      rb[j] = ld_buf(xr, ok ? xo : OOB);
-    }
-    __syncthreads();  // previous chunk's MFMAs have read the tiles
+      const unsigned base = (nA < p.N) ? (unsigned)(bA * p.Mtot * p.OHW + pixA) * 4u : OOB;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-    {
-      As[(r0 + 16 * j) * LS + nl] = ra[j];
-      Bs[(r0 + 16 * j) * LS + nl] = rb[j];
+      for (int j = 0; j < PA; ++j)
+      {
+        u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(dr, (int)((base + roff[j]) | ((base | roff[j]) & OOB)), 0, 0);
+        ra[4 * j + 0] = __uint_as_float(v.x);
+        ra[4 * j + 1] = __uint_as_float(v.y);
+        ra[4 * j + 2] = __uint_as_float(v.z);
+        ra[4 * j + 3] = __uint_as_float(v.w);
+      }
     }
+    else
+    {
+      const unsigned base = (n < p.N) ? (unsigned)(b * p.Mtot * p.OHW + pix) * 4u : OOB;
+#pragma unroll
+      for (int j = 0; j < PA; ++j) ra[j] = ld_buf(dr, (base + roff[j]) | ((base | roff[j]) & OOB));
+    }
+    // col: padding mask of this pixel (bit t set <=> tap t is outside the image)
+    const int iy0 = oy * p.stride_y - p.pad, ix0 = ox * p.stride_x - p.pad;
+    unsigned colbits = 0, okbits = 0;
+    for (int kw = 0; kw < p.size; ++kw)
+      colbits |= ((unsigned)(ix0 + kw * p.dil) < (unsigned)p.W ? 1u : 0u) << kw;
+    for (int kh = 0; kh < p.size; ++kh)
+      if ((unsigned)(iy0 + kh * p.dil) < (unsigned)p.H)
+        okbits |= colbits << (kh * p.size);
+    const unsigned nmask = (n < p.N) ? ~okbits : 0xFFFFFFFFu;
+    const unsigned xbase = (unsigned)((b * p.Ctot + g * p.C) * HW + iy0 * p.W + ix0) * 4u;
+#pragma unroll
+    for (int j = 0; j < PB; ++j)
+      rb[j] = ld_buf(xr, (xbase + toff[j]) | (((nmask << tsh[j]) | toff[j]) & OOB));
+  };
+
+  auto advance = [&]() {
+    n += NC;
+    pix += NC;
+    ox += NC;
+    while (ox >= p.OW)
+    {
+      ox -= p.OW;
+      ++oy;
+    }
+    while (pix >= p.OHW)
+    {
+      pix -= p.OHW;
+      ++b;
+      oy = pix / p.OW;
+      ox = pix - oy * p.OW;
+    }
+    if (AVEC)
+    {
+      nA += NC;
+      pixA += NC;
+      while (pixA >= p.OHW)
+      {
+        pixA -= p.OHW;
+        ++bA;
+      }
+    }
+  };
+
+  auto store_stage = [&](float* stg) {
+    float* As = stg;
+    float* Bs = stg + A_FL;
+    if (AVEC)
+    {
+#pragma unroll
+      for (int j = 0; j < PA; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) As[(ar + 32 * j) * LS + 4 * aq + e] = ra[4 * j + e];
+    }
+    else
+    {
+#pragma unroll
+      for (int j = 0; j < PA; ++j) As[(ar + 8 * j) * LS + nl] = ra[j];
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j) Bs[(r8 + 8 * j) * LS + nl] = rb[j];
+  };
+
+  f32x16 acc[TM][TK];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TK; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (st_begin < st_end)
+  {
+    load_stage();
+    advance();
+    store_stage(lds);
     __syncthreads();
-    // A operand: lane (i = m, kk = n) ; B operand: lane (kk = n, j = k)
-    const float* ap = As + (wm * 32 + l31) * LS + lh;
-    const float* bp = Bs + (wk * 32 + l31) * LS + lh;
+    for (int st = st_begin; st < st_end; ++st)
+    {
+      float* cur = lds + ((st - st_begin) & 1) * STAGE;
+      const bool more = (st + 1) < st_end;
+      if (more)
+      {
+        load_stage();
+        advance();
+      }
+      // A operand: lane (row m, kk = n); B operand: lane (kk = n, col k)
+      const float* ap = cur + (wm * 32 * TM + l31) * LS + lh;
+      const float* bp = cur + A_FL + (wk * 32 * TK + l31) * LS + lh;
 #pragma unroll
-    for (int s = 0; s < NC / 2; ++s)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bp[2 * s], acc, 0, 0, 0);
+      for (int s = 0; s < NC / 2; ++s)
+      {
+        float a[TM], bb[TK];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = ap[i * 32 * LS + 2 * s];
+#pragma unroll
+        for (int j = 0; j < TK; ++j) bb[j] = bp[j * 32 * LS + 2 * s];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TK; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+      }
+      if (more)
+        store_stage(lds + ((st + 1 - st_begin) & 1) * STAGE);
+      __syncthreads();
+    }
   }
 
   // C/D: col (= k) = lane&31, row (= m) = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  const int k = k0 + wk * 32 + l31;
-  if (k < p.K)
-  {
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-    {
-      const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (m < p.M)
-        atomicAdd(&p.dw[((size_t)g * p.M + m) * p.K + k], acc[r]);
-    }
+  for (int j = 0; j < TK; ++j)
+  {
+    const int k = k0 + (wk * TK + j) * 32 + l31;
+    if (k >= p.K)
+      continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+      {
+        const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < p.M)
+          atomicAdd(&p.dw[((size_t)g * p.M + m) * p.K + k], acc[i][j][r]);
+      }
   }
 }
+
+typedef void (*WgradKernel)(const WgradArgs);
+struct WgradCfg
+{
+  int tm, tk;
+  WgradKernel kernel[2];  // [AVEC]
+};
+const WgradCfg g_wcfg[] = {
+    {2, 2, {conv_wgrad_f32<2, 2, false>, conv_wgrad_f32<2, 2, true>}},
+    {1, 2, {conv_wgrad_f32<1, 2, false>, conv_wgrad_f32<1, 2, true>}},
+    {2, 1, {conv_wgrad_f32<2, 1, false>, conv_wgrad_f32<2, 1, true>}},
+    {1, 1, {conv_wgrad_f32<1, 1, false>, conv_wgrad_f32<1, 1, true>}},
+};
 }  // namespace
 
 extern "C" int dk_conv_backward_weights(const DkConvDesc* d, const float* x, const float* delta,
@@ -189,20 +324,31 @@ extern "C" int dk_conv_backward_weights(const DkConvDesc* d, const float* x, con
     a.N = nb * OH * OW;
     a.size = d->size; a.stride_x = d->stride_x; a.stride_y = d->stride_y;
     a.pad = pad; a.dil = d->dilation;
+    const int ci = (M > 64 ? 0 : 1) + (K > 64 ? 0 : 2);  // 128/64 rows x 128/64 taps
+    const WgradCfg& c = g_wcfg[ci];
+    const int BM = 64 * c.tm, BKO = 64 * c.tk;
     a.tiles_m = (M + BM - 1) / BM;
     a.tiles_k = (K + BKO - 1) / BKO;
     a.groups = d->groups;
-    const int nchunks = (a.N + NC - 1) / NC;
+    const int nstages = (a.N + NC - 1) / NC;
     const long long tiles = (long long)a.tiles_m * a.tiles_k * d->groups;
-    long long want = (2048 + tiles - 1) / tiles;  // ~8 workgroups per CU in total
+    long long want = (1024 + tiles - 1) / tiles;  // ~4 workgroups per CU in total
     if (want < 1) want = 1;
-    if (want > nchunks) want = nchunks;
-    a.chunks_per_split = (int)((nchunks + want - 1) / want);
-    if (a.chunks_per_split < 8 && nchunks >= 8)
-      a.chunks_per_split = 8;
-    a.nsplit = (nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
+    if (want > nstages) want = nstages;
+    a.stages_per_split = (int)((nstages + want - 1) / want);
+    if (a.stages_per_split < 8 && nstages >= 8)
+      a.stages_per_split = 8;
+    a.nsplit = (nstages + a.stages_per_split - 1) / a.stages_per_split;
     const long long nblk = tiles * a.nsplit;
-    hipLaunchKernelGGL(conv_wgrad_f32, dim3((unsigned)nblk), dim3(T), 0, st, a);
+    const bool avec = (a.OHW % 4 == 0) && (((uintptr_t)a.delta & 15) == 0);
+    const int lds_bytes = 2 * (BM + BKO) * LS * (int)sizeof(float);
+    static bool attr_set[4][2];
+    if (!attr_set[ci][avec])
+    {
+      CHECK_HIP(hipFuncSetAttribute((const void*)c.kernel[avec], hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+      attr_set[ci][avec] = true;
+    }
+    hipLaunchKernelGGL(c.kernel[avec], dim3((unsigned)nblk), dim3(T), lds_bytes, st, a);
     CHECK_HIP(hipPeekAtLastError());
   }
   return 0;

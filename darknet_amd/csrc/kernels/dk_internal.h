@@ -25,3 +25,4 @@ int dk_conv_num_configs();
 // true when tile configuration `cfg` can run this layer (the direct 3x3 configurations,
 // indices >= the number of gather configurations, only take 3x3/s1/p1 layers)
 bool dk_conv_config_applicable(const DkConvDesc* d, int cfg);
+int dk_transpose_weights_flip(const float* w, float* wt, int M, int C, int size, void* stream);

@@ -26,6 +26,7 @@
 
 #include "dark_hip.h"
 #include "dk_kernels.h"
+#include "dk_internal.h"
 #include "dk_device_math.h"
 
 namespace
@@ -383,7 +384,7 @@ __global__ void sgd_kernel(float* __restrict__ w, float* __restrict__ wu, size_t
 
 // Wt[c][(m, t)] = W[m][c][t]  (t = kh*size + kw), per group
 __global__ void transpose_w_kernel(const float* __restrict__ w, float* __restrict__ wt, int M, int C,
-    int ss, size_t total)
+    int ss, size_t total, int flip)
 {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
        i += (size_t)gridDim.x * blockDim.x)
@@ -392,7 +393,7 @@ __global__ void transpose_w_kernel(const float* __restrict__ w, float* __restric
     const size_t r = i / ss;
     const int m = (int)(r % M);
     const int c = (int)(r / M);
-    wt[i] = w[((size_t)m * C + c) * ss + t];
+    wt[i] = w[((size_t)m * C + c) * ss + (flip ? ss - 1 - t : t)];
   }
 }
 }  // namespace
@@ -546,7 +547,20 @@ extern "C" int dk_transpose_weights(const float* w, float* wt, int M, int C, int
   if (total == 0)
     return 0;
   hipLaunchKernelGGL(transpose_w_kernel, dim3(grid_for(total)), dim3(256), 0, S(stream), w, wt, M,
-      C, size * size, total);
+      C, size * size, total, 0);
+  CHECK_HIP(hipPeekAtLastError());
+  return 0;
+}
+
+// wt[c][(m, t)] = w[m][c][ss-1-t]: the weights of the convolution that computes the data
+// gradient of a stride-1 "same" convolution (taps rotated by 180 degrees)
+int dk_transpose_weights_flip(const float* w, float* wt, int M, int C, int size, void* stream)
+{
+  const size_t total = (size_t)M * C * size * size;
+  if (total == 0)
+    return 0;
+  hipLaunchKernelGGL(transpose_w_kernel, dim3(grid_for(total)), dim3(256), 0, S(stream), w, wt, M,
+      C, size * size, total, 1);
   CHECK_HIP(hipPeekAtLastError());
   return 0;
 }

@@ -76,6 +76,8 @@ DIRECT_CASES = [
     (1, 4, 152, 152, 32, "LINEAR"),   # pitch 160
     (2, 16, 64, 64, 64, "MISH"),      # pitch 80, W a power of two
     (1, 4, 26, 26, 16, "LEAKY"),      # pitch 40, N = 676 (ragged last tile)
+    (3, 8, 13, 13, 32, "LEAKY"),      # 416-net sizes: pitch 24 with 169-pixel images
+    (1, 8, 52, 52, 32, "MISH"),       # pitch 80, 8 patch rows
 ]
 
 
