@@ -1,0 +1,14 @@
+#!/bin/bash
+# Dev tool (GPU box): SQ counters of ONE conv layer/config, one rocprofv3 --pmc pass per group.
+# usage: tools/pmc_one.sh OUTDIR batch c h w n size stride pad act cfg
+R=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$1; shift
+mkdir -p $R/$OUT; cd /tmp && export TMPDIR=/tmp
+i=0
+for grp in "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVES" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS" \
+           "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES" \
+           "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $R/$OUT/g$i -- python3 $R/tools/conv_one.py "$@" 6 > $R/$OUT/g$i.log 2>&1 || exit 1
+done
