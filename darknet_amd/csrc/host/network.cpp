@@ -367,11 +367,13 @@ void ForwardNetworkGpu(Network* net, NetworkState state)
 {
   state.workspace = net->workspace;
   hipStream_t st = get_cuda_stream();
+  if (state.train && net->delta_arena_gpu)
+    CHECK_HIP(hipMemsetAsync(net->delta_arena_gpu, 0, net->delta_arena_size * sizeof(float), st));
   for (int i = 0; i < net->n; ++i)
   {
     state.index = i;
     layer* l = &net->layers[i];
-    if (l->delta_gpu && state.train)
+    if (l->delta_gpu && state.train && !l->delta_in_arena)
       CHECK_HIP(hipMemsetAsync(l->delta_gpu, 0, (size_t)l->outputs * l->batch * sizeof(float), st));
     std::chrono::steady_clock::time_point t0;
     if (net->benchmark_layers)
@@ -643,6 +645,7 @@ void FreeNetwork(Network* net)
       cuda_free_host(net->input_pinned_cpu);
     cuda_free(net->workspace);
     cuda_free(net->wt_scratch_gpu);
+    cuda_free(net->delta_arena_gpu);
   }
   memset(net, 0, sizeof(*net));
 }

@@ -410,6 +410,29 @@ static bool parse_cfg_batch(Network* net, char const* filename, bool train, int 
         if (net->layers[i].type == CONVOLUTIONAL && (size_t)net->layers[i].nweights > maxw)
           maxw = net->layers[i].nweights;
       net->wt_scratch_gpu = cuda_make_array(0, maxw);
+      // one arena for all delta tensors: the per-layer zero-fills of the forward pass
+      // (forward_network_gpu's fill_ongpu per layer, network_kernels.cu:79) become one memset
+      size_t tot = 0;
+      for (int i = 0; i < net->n; ++i)
+        if (net->layers[i].delta_gpu)
+          tot += (((size_t)net->layers[i].outputs * net->layers[i].batch + 63) / 64) * 64;
+      if (tot)
+      {
+        net->delta_arena_gpu = cuda_make_array(0, tot);
+        net->delta_arena_size = tot;
+        size_t off = 0;
+        for (int i = 0; i < net->n; ++i)
+        {
+          layer* l = &net->layers[i];
+          if (!l->delta_gpu)
+            continue;
+          cuda_free(l->delta_gpu);
+          l->delta_gpu = net->delta_arena_gpu + off;
+          l->delta_in_arena = 1;
+          off += (((size_t)l->outputs * l->batch + 63) / 64) * 64;
+        }
+        CHECK_HIP(hipMemsetAsync(net->delta_arena_gpu, 0, tot * sizeof(float), get_cuda_stream()));
+      }
     }
     CHECK_HIP(hipStreamSynchronize(get_cuda_stream()));
   }

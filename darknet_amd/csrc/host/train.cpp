@@ -49,9 +49,9 @@ void ForwardConvTrainGpu(layer* l, NetworkState state)
   DkConvDesc d = conv_desc_of(l, (int)LINEAR);
   if (dk_conv_forward_cfg(&d, state.input, l->weights_gpu, nullptr, raw, nullptr, nullptr, st, -1))
     error("ForwardConvolutionalLayerGpu (train) failed");
-  float* act_in = (state.train && l->activation_input_gpu) ? l->activation_input_gpu : nullptr;
+  // x_norm / pre-activation are not stored: the fused backward recomputes them from x
   const int train = state.train && !temp;
-  if (dk_bn_forward_train(raw, raw, l->x_norm_gpu, act_in, l->output_gpu, l->mean_gpu,
+  if (dk_bn_forward_train(raw, nullptr, nullptr, nullptr, l->output_gpu, l->mean_gpu,
           l->variance_gpu, l->rolling_mean_gpu, l->rolling_variance_gpu, l->scales_gpu,
           l->biases_gpu, l->batch, l->n, spatial, (int)l->activation, train, st))
     error("batch-norm forward failed");
@@ -63,18 +63,20 @@ void BackwardConvolutionalLayerGpu(layer* l, NetworkState state)
   hipStream_t st = get_cuda_stream();
   const int spatial = l->out_h * l->out_w;
   const size_t total = (size_t)l->batch * l->outputs;
-  if (dk_gradient_array(l->output_gpu, l->activation_input_gpu, l->delta_gpu, total,
-          (int)l->activation, st))
-    error("activation gradient failed");
   if (l->batch_normalize)
   {
-    if (dk_bn_backward(l->delta_gpu, l->x_gpu, l->x_norm_gpu, l->mean_gpu, l->variance_gpu,
-            l->scales_gpu, l->mean_delta_gpu, l->variance_delta_gpu, l->scale_updates_gpu,
-            l->bias_updates_gpu, l->batch, l->n, spatial, st))
-      error("batch-norm backward failed");
+    if (dk_bn_act_backward(l->delta_gpu, l->x_gpu, l->mean_gpu, l->variance_gpu, l->scales_gpu,
+            l->biases_gpu, l->mean_delta_gpu, l->variance_delta_gpu, l->scale_updates_gpu,
+            l->bias_updates_gpu, l->batch, l->n, spatial, (int)l->activation, st))
+      error("activation + batch-norm backward failed");
   }
   else
+  {
+    if (dk_gradient_array(l->output_gpu, l->activation_input_gpu, l->delta_gpu, total,
+            (int)l->activation, st))
+      error("activation gradient failed");
     dk_backward_bias(l->bias_updates_gpu, l->delta_gpu, l->batch, l->n, spatial, st);
+  }
 
   DkConvDesc d = conv_desc_of(l, (int)LINEAR);
   if (dk_conv_backward_weights(&d, state.input, l->delta_gpu, l->weight_updates_gpu, st))

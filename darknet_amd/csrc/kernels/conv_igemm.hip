@@ -424,6 +424,12 @@ bool fast_mish()
   return v == 1;
 }
 
+}  // namespace
+
+bool dk_fast_mish_enabled() { return fast_mish(); }
+
+namespace
+{
 int out_dim(int in, int pad, int size, int stride) { return (in + 2 * pad - size) / stride + 1; }
 
 int env_cfg()

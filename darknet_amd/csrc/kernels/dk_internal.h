@@ -26,3 +26,5 @@ int dk_conv_num_configs();
 // indices >= the number of gather configurations, only take 3x3/s1/p1 layers)
 bool dk_conv_config_applicable(const DkConvDesc* d, int cfg);
 int dk_transpose_weights_flip(const float* w, float* wt, int M, int C, int size, void* stream);
+// DK_FAST_MISH (default on): closed-form mish / mish gradient instead of the libm chains
+bool dk_fast_mish_enabled();

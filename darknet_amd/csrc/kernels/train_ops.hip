@@ -304,6 +304,125 @@ __global__ void bn_delta_kernel(float* __restrict__ delta, const float* __restri
   }
 }
 
+
+// ---- fused activation-gradient + batch-norm backward ---------------------------------
+// Nothing but x (the raw conv output) was saved in the forward pass: x_norm, the
+// pre-activation input and the activation gradient are recomputed with the forward's
+// own float operations (same values as the stored ones would have), so the backward
+// of activation + batch norm reads {delta, x} twice and writes delta once instead of
+// the separate gradient_array / reductions / normalize_delta passes (9 streams -> 5)
+// and the forward writes only its output (5 streams -> 2).
+struct BnRecompute
+{
+  float xn, d;  // x_norm, delta * activation gradient
+};
+
+__device__ __forceinline__ BnRecompute bn_recompute(float x, float delta, float mean, float inv_fwd,
+    float scale, float bias, int act)
+{
+  BnRecompute r;
+  (void)inv_fwd;
+  r.xn = (x - mean) / inv_fwd;  // inv_fwd = sqrtf(variance + 1e-6f): the forward's divisor
+  float a = r.xn * scale;
+  a = a + bias;
+  float g;
+  if (act == (DK_MISH | DK_ACT_FAST))
+  {
+    // gradient_array_mish in closed form (one exp, two reciprocals): with e = exp(a),
+    // w = e(e+2): tanh(softplus(a)) = w/(w+2), 1-exp(-softplus(a)) = e/(1+e).
+    // Differs from the libm chain below by ~1e-7 relative; DK_FAST_MISH=0 selects that.
+    const float e = __expf(a);
+    const float w = e * (e + 2.f);
+    const float tsp = (a > 20.f) ? 1.f : w * __builtin_amdgcn_rcpf(w + 2.f);
+    const float grad_sp = (a > 20.f) ? 1.f : e * __builtin_amdgcn_rcpf(1.f + e);
+    g = a * ((1 - tsp * tsp) * grad_sp) + tsp;
+  }
+  else if ((act & 0xff) == DK_MISH)
+  {
+    const float sp = dk_softplus(a, 20.f);
+    const float grad_sp = 1 - expf(-sp);
+    const float tsp = tanhf(sp);
+    const float grad_tsp = (1 - tsp * tsp) * grad_sp;
+    g = a * grad_tsp + tsp;
+  }
+  else if (act == DK_LEAKY)
+    g = (dk_leaky(a) > 0) ? 1 : .1f;
+  else if (act == DK_LOGISTIC)
+  {
+    const float y = dk_logistic(a);
+    g = (1 - y) * y;
+  }
+  else if (act == DK_RELU)
+    g = (a * (a > 0.f) > 0);
+  else
+    g = 1;
+  r.d = delta * g;
+  return r;
+}
+
+__global__ void __launch_bounds__(RT) bn_act_partial_kernel(const float* __restrict__ delta,
+    const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ variance,
+    const float* __restrict__ scales, const float* __restrict__ biases, int batch, int filters,
+    int spatial, size_t slice, double* __restrict__ scratch, int act)
+{
+  __shared__ double sh[RT / 64];
+  const int f = blockIdx.y;
+  const size_t n = (size_t)batch * spatial;
+  const size_t t0 = blockIdx.x * slice;
+  size_t t1 = t0 + slice;
+  if (t1 > n)
+    t1 = n;
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  const float sc = scales[f], bi = biases[f], m = mean[f];
+  const float div = sqrtf(variance[f] + .000001f);
+  for (size_t t = t0 + threadIdx.x; t < t1; t += RT)
+  {
+    const size_t idx = chan_index(t, f, filters, spatial);
+    const float xv = x[idx];
+    const BnRecompute r = bn_recompute(xv, delta[idx], m, div, sc, bi, act);
+    s0 += r.d;
+    s1 += r.d * r.xn;
+    const float ds = r.d * sc;
+    s2 += ds;
+    s3 += ds * (xv - m);
+  }
+  s0 = block_sum(s0, sh);
+  s1 = block_sum(s1, sh);
+  s2 = block_sum(s2, sh);
+  s3 = block_sum(s3, sh);
+  if (threadIdx.x == 0)
+  {
+    atomicAdd(&scratch[4 * f + 0], s0);
+    atomicAdd(&scratch[4 * f + 1], s1);
+    atomicAdd(&scratch[4 * f + 2], s2);
+    atomicAdd(&scratch[4 * f + 3], s3);
+  }
+}
+
+// grid (chunks, batch*filters): one (image, channel) plane per blockIdx.y -> no per-element division
+__global__ void bn_act_delta_kernel(float* __restrict__ delta, const float* __restrict__ x,
+    const float* __restrict__ mean, const float* __restrict__ variance,
+    const float* __restrict__ mean_delta, const float* __restrict__ variance_delta,
+    const float* __restrict__ scales, const float* __restrict__ biases, int batch, int filters,
+    int spatial, int act)
+{
+  const int plane = blockIdx.y;
+  const int f = plane % filters;
+  const int nb = spatial * batch;
+  const float sc = scales[f], bi = biases[f], m = mean[f], var = variance[f];
+  const float div = sqrtf(var + .000001f);
+  const float vd = variance_delta[f], md = mean_delta[f];
+  float* dp = delta + (size_t)plane * spatial;
+  const float* xp = x + (size_t)plane * spatial;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < spatial; i += gridDim.x * blockDim.x)
+  {
+    const float xv = xp[i];
+    const BnRecompute r = bn_recompute(xv, dp[i], m, div, sc, bi, act);
+    const float ds = r.d * sc;
+    dp[i] = ds * 1. / (sqrtf(var) + .00001f) + vd * 2. * (xv - m) / nb + md / nb;
+  }
+}
+
 // ---- backward of the glue layers ----------------------------------------------------
 __global__ void maxpool_bwd_kernel(const float* __restrict__ delta, const int* __restrict__ indexes,
     size_t n, float* __restrict__ prev_delta)
@@ -479,6 +598,35 @@ extern "C" int dk_bn_backward(float* delta, const float* x, const float* x_norm,
   CHECK_HIP(hipPeekAtLastError());
   hipLaunchKernelGGL(bn_delta_kernel, dim3(grid_for(total)), dim3(256), 0, st, delta, x,
       mean, variance, mean_delta, variance_delta, scales, batch, filters, spatial, total);
+  CHECK_HIP(hipPeekAtLastError());
+  return 0;
+}
+
+// gradient_array + backward_batchnorm in one (see bn_recompute): `delta` holds the
+// gradient w.r.t. the layer's OUTPUT on entry and w.r.t. the raw conv output x on exit.
+extern "C" int dk_bn_act_backward(float* delta, const float* x, const float* mean,
+    const float* variance, const float* scales, const float* biases, float* mean_delta,
+    float* variance_delta, float* scale_updates, float* bias_updates, int batch, int filters,
+    int spatial, int activation, void* stream)
+{
+  const size_t total = (size_t)batch * filters * spatial;
+  if (total == 0)
+    return 0;
+  hipStream_t st = S(stream);
+  if (activation == DK_MISH && dk_fast_mish_enabled())
+    activation |= DK_ACT_FAST;
+  double* scratch = chan_scratch(filters, st);
+  int chunks;
+  size_t slice;
+  chan_split(batch, filters, spatial, &chunks, &slice);
+  hipLaunchKernelGGL(bn_act_partial_kernel, dim3(chunks, filters), dim3(RT), 0, st, delta, x, mean,
+      variance, scales, biases, batch, filters, spatial, slice, scratch, activation);
+  hipLaunchKernelGGL(chan_finalize_kernel, dim3((filters + 255) / 256), dim3(256), 0, st, scratch,
+      variance, filters, bias_updates, scale_updates, mean_delta, variance_delta, 1);
+  int gx = (spatial + 1023) / 1024;
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(bn_act_delta_kernel, dim3(gx, batch * filters), dim3(256), 0, st, delta, x, mean,
+      variance, mean_delta, variance_delta, scales, biases, batch, filters, spatial, activation);
   CHECK_HIP(hipPeekAtLastError());
   return 0;
 }

@@ -148,6 +148,13 @@ DK_API int dk_backward_bias(float* bias_updates, const float* delta, int batch, 
 DK_API int dk_bn_backward(float* delta, const float* x, const float* x_norm, const float* mean,
     const float* variance, const float* scales, float* mean_delta, float* variance_delta,
     float* scale_updates, float* bias_updates, int batch, int filters, int spatial, void* stream);
+/* gradient_array + backward_batchnorm fused (activations.c:401-452 + batchnorm_layer.cpp:240-255):
+ * x_norm, the pre-activation value and the activation gradient are recomputed from x with the
+ * forward's own float operations instead of being stored; delta: d/d(output) in, d/d(x) out. */
+DK_API int dk_bn_act_backward(float* delta, const float* x, const float* mean, const float* variance,
+    const float* scales, const float* biases, float* mean_delta, float* variance_delta,
+    float* scale_updates, float* bias_updates, int batch, int filters, int spatial, int activation,
+    void* stream);
 /* Weight gradient: weight_updates[m][k] += sum_n delta[m][n]*im2col(x)[k][n] (wgrad half of
  * BackwardConvolutionalLayerGpu, src/convolutional_kernels.cu:757-781). */
 DK_API int dk_conv_backward_weights(const DkConvDesc* d, const float* x, const float* delta,

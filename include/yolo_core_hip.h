@@ -198,6 +198,7 @@ struct layer
   int conv_cfg;          /* tile configuration chosen by the autotuner, or -1 */
   /* zero-copy concatenation (inference plan): a producer whose only reader is a multi-input
    * [route] writes straight into that route's buffer; a single-input [route] is an alias */
+  int delta_in_arena;    /* delta_gpu points into net->delta_arena_gpu (not freed per layer) */
   float* out_view;       /* producer: where the output really goes (a channel slice), or NULL */
   int out_view_ctot;     /* producer: channels of the tensor out_view is a slice of */
   float* out_alias;      /* route with one input: the source's buffer, or NULL */
@@ -248,6 +249,8 @@ struct Network
   void* graph_exec;      /* hipGraphExec_t of the captured forward, or NULL */
   int graph_batch;
   float* wt_scratch_gpu; /* transposed weights of the layer whose data gradient is running */
+  float* delta_arena_gpu; /* train: every layer's delta_gpu lives in this one allocation (one memset per step) */
+  size_t delta_arena_size;
   float* grad_bucket;    /* caller-owned contiguous gradient bucket (DkAttachGradBucket), or NULL */
 };
 

@@ -83,6 +83,35 @@ def test_tiny_b4_batched_vs_oracle(gpu, weights):
     net.close()
 
 
+def test_tiny_b32_config_c2(gpu, weights):
+    """BASELINE configs[1]: yolov4-tiny 416x416 batch=32 on one GPU.  Item 0 == the reference's
+    b=1 golden run (heads, detection indices, class ids), every item identical, mixed batch
+    (distinct images) == the CPU oracle on a sample of items."""
+    name, B = "yolov4-tiny", 32
+    g = np.load(os.path.join(GOLD, "net_%s.npz" % name))
+    net = netutil.DkNet(gpu, netutil.cfg_path(name), weights[name], batch=B)
+    x1 = synth.make_input(1, net.c, net.h, net.w)
+    net.predict(np.repeat(x1, B, 0))
+    net.predict(np.repeat(x1, B, 0))  # graph replay
+    for i in (30, 37):
+        o = net.output(i)
+        assert all(np.array_equal(o[0], o[k]) for k in range(1, B)), "output depends on batch position"
+        util.assert_close(o[0].ravel(), g["head_%d" % i].ravel(), "tiny b=32 item 0 vs golden head %d" % i)
+    dets, ids = net.boxes(B - 1, float(g["thresh"]))
+    assert np.array_equal(ids, g["det_ids"])
+    assert np.array_equal(np.argmax(dets[:, 5:], 1), g["det_best_class"])
+    # distinct images: items 0, 13, 31 against the oracle run one image at a time
+    x = synth.make_input(B, net.c, net.h, net.w, seed=4242)
+    net.predict(x)
+    onet = O.load_network(netutil.cfg_path(name), weights[name], batch=1)
+    for b in (0, 13, 31):
+        O.forward(onet, x[b:b + 1])
+        for i, l in enumerate(onet.layers):
+            if l.type == O.YOLO:
+                util.assert_close(net.output(i)[b], l.output[0], "tiny b=32 item %d head %d" % (b, i))
+    net.close()
+
+
 def check_dets_guarded(dets, ids, odets, oids, thresh, what, guard=1e-3):
     def key(i4):
         return [tuple(r) for r in i4]

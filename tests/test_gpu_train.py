@@ -25,6 +25,7 @@ def bind(L):
         "dk_gradient_array": [VP, VP, VP, sz, i, VP],
         "dk_backward_bias": [VP, VP, i, i, i, VP],
         "dk_bn_backward": [VP] * 10 + [i, i, i, VP],
+        "dk_bn_act_backward": [VP] * 10 + [i, i, i, i, VP],
         "dk_conv_backward_weights": [VP, VP, VP, VP, VP],
         "dk_conv_backward_data": [VP, VP, VP, VP, VP],
         "dk_transpose_weights": [VP, VP, i, i, i, VP],
@@ -133,6 +134,24 @@ def test_batchnorm_forward_backward_vs_oracle(gpu):
         util.assert_close(dd.numpy().reshape(raw.shape), rdelta, "bn delta")
         # quirk 3: the CPU reference never fills bias_updates for BN layers; here it is the true sum(delta)
         util.assert_close(dbu.numpy(), delta.sum(axis=(0, 2), dtype=np.float64).astype(np.float32), "bias_updates", rel=2e-5)
+        # fused activation-gradient + BN backward (recomputes x_norm / pre-activation from x):
+        # oracle = gradient_array on the output delta, then backward_batchnorm
+        gdelta = delta.copy()
+        if act == O.MISH:
+            L.orc_gradient_array_mish(pre.size, O.fptr(pre), O.fptr(gdelta))
+        else:
+            L.orc_gradient_array(O.fptr(out), out.size, act, O.fptr(gdelta))
+        su2 = su0.copy()
+        md2, vd2 = np.zeros(c, np.float32), np.zeros(c, np.float32)
+        gsum = gdelta.sum(axis=(0, 2), dtype=np.float64).astype(np.float32)
+        L.orc_batchnorm_backward(O.fptr(gdelta), batch, c, sp, O.fptr(scales), O.fptr(xs), O.fptr(xn), O.fptr(mean),
+                                 O.fptr(var), O.fptr(md2), O.fptr(vd2), O.fptr(su2))
+        fd, fsu, fbu = gpu.DeviceArray(delta), gpu.DeviceArray(su0), gpu.DeviceArray(np.zeros(c, np.float32))
+        assert G.dk_bn_act_backward(fd.ptr, dxs.ptr, dm.ptr, dv.ptr, d["sc"].ptr, d["bi"].ptr, dmd.ptr, dvd.ptr,
+                                    fsu.ptr, fbu.ptr, batch, c, sp, act, None) == 0
+        util.assert_close(fsu.numpy(), su2, "fused scale_updates", rel=2e-5)
+        util.assert_close(fbu.numpy(), gsum, "fused bias_updates", rel=2e-5)
+        util.assert_close(fd.numpy().reshape(raw.shape), gdelta, "fused act+bn delta")
 
 
 def test_glue_backward_and_sgd(gpu):
