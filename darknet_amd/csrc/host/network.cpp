@@ -422,6 +422,7 @@ void NetworkPredictDevice(Network* net, float* input_gpu)
   const int dev = net->gpu_index;
   ensure_events(dev);
   hipStream_t st = get_cuda_stream();
+  net->predict_seq++;
   NetworkState state;
   memset(&state, 0, sizeof(state));
   state.net = net;
@@ -512,11 +513,187 @@ float* NetworkPredictGpu(Network* net, float* input)
 
 float* NetworkPredict(Network* net, float* input) { return NetworkPredictGpu(net, input); }
 
+// the input step before the path.  The frames cross PCIe as bytes (4x fewer
+// than floats) and Mat2Image's arithmetic runs on the device.
+void DkNetworkPredictU8(Network* net, const unsigned char* frames_hwc, size_t row_step)
+{
+  if (net->gpu_index < 0)
+    error("DkNetworkPredictU8: no HIP device (this library has no CPU fallback)");
+  if (net->gpu_index != cuda_get_device())
+    cuda_set_device(net->gpu_index);
+  if (row_step < (size_t)net->w * net->c)
+    error("DkNetworkPredictU8: row_step smaller than one row");
+  const size_t bytes = row_step * net->h * net->batch;
+  if (net->u8_bytes < bytes)
+  {
+    if (net->u8_gpu) CHECK_HIP(hipFree(net->u8_gpu));
+    if (net->u8_pinned) CHECK_HIP(hipHostFree(net->u8_pinned));
+    CHECK_HIP(hipMalloc((void**)&net->u8_gpu, bytes));
+    CHECK_HIP(hipHostMalloc((void**)&net->u8_pinned, bytes, hipHostMallocDefault));
+    net->u8_bytes = bytes;
+  }
+  hipStream_t st = get_cuda_stream();
+  CHECK_HIP(hipStreamSynchronize(st));  // the previous call's H2D out of the staging buffer is done
+  memcpy(net->u8_pinned, frames_hwc, bytes);
+  CHECK_HIP(hipMemcpyAsync(net->u8_gpu, net->u8_pinned, bytes, hipMemcpyHostToDevice, st));
+  if (dk_image_u8_to_chw(net->u8_gpu, net->input_state_gpu, net->batch, net->w, net->h, net->c, row_step, st))
+    error("dk_image_u8_to_chw failed");
+  NetworkPredictDevice(net, nullptr);
+}
+
 // ---------------------------------------------------------------------------
 // detections (host C++, as in the reference)
 // ---------------------------------------------------------------------------
+
+// ---------------------------------------------------------------------------
+// device-side candidate extraction: with DkSetPullHeads(0) the decoded
+// heads stay in HBM; GetNetworkBoxes* compacts the predictors above the threshold on the
+// device (dk_yolo_compact), copies the few records out, orders them as the reference's
+// scan does (layer, anchor, cell) and applies the reference's box arithmetic on the host:
+// same Detection arrays, ~100 KB instead of the whole head across PCIe.
+// ---------------------------------------------------------------------------
+static void ensure_candidates(Network* net, float thresh)
+{
+  if (net->cand_valid && net->cand_seq == net->predict_seq && net->cand_thresh == thresh)
+    return;
+  int classes = -1;
+  bool uniform = true;
+  for (int i = 0; i < net->n; ++i)
+    if (net->layers[i].type == YOLO)
+    {
+      if (classes < 0)
+        classes = net->layers[i].classes;
+      else if (classes != net->layers[i].classes)
+        uniform = false;
+    }
+  hipStream_t st = get_cuda_stream();
+  net->cand_fallback = 0;
+  net->cand_count = 0;
+  if (classes < 0)
+  {
+    net->cand_valid = 1; net->cand_seq = net->predict_seq; net->cand_thresh = thresh;
+    return;
+  }
+  const int rec = 3 + 5 + classes;
+  if (!net->cand_gpu || net->cand_rec != rec)
+  {
+    net->cand_cap = 65536;
+    net->cand_rec = rec;
+    cuda_free(net->cand_gpu);
+    if (net->cand_host) cuda_free_host(net->cand_host);
+    free(net->cand_order);
+    net->cand_gpu = cuda_make_array(nullptr, (size_t)net->cand_cap * rec);
+    net->cand_host = cuda_make_array_pinned(nullptr, (size_t)net->cand_cap * rec);
+    net->cand_order = (int*)xcalloc(net->cand_cap, sizeof(int));
+    if (!net->cand_counter_gpu)
+      net->cand_counter_gpu = cuda_make_int_array(1);
+  }
+  int count = 0;
+  if (uniform)
+  {
+    CHECK_HIP(hipMemsetAsync(net->cand_counter_gpu, 0, sizeof(int), st));
+    for (int i = 0; i < net->n; ++i)
+    {
+      layer* l = &net->layers[i];
+      if (l->type == YOLO)
+        if (dk_yolo_compact(l->output_gpu, l->batch, l->w, l->h, l->n, l->classes, thresh, i, net->cand_gpu,
+                net->cand_counter_gpu, net->cand_cap, st))
+          error("dk_yolo_compact failed");
+    }
+    CHECK_HIP(hipMemcpyAsync(&count, net->cand_counter_gpu, sizeof(int), hipMemcpyDeviceToHost, st));
+    CHECK_HIP(hipStreamSynchronize(st));
+  }
+  if (!uniform || count > net->cand_cap)
+  {
+    // too many candidates (or mixed heads): fall back to pulling the whole heads
+    for (int i = 0; i < net->n; ++i)
+    {
+      layer* l = &net->layers[i];
+      if (l->type == YOLO)
+        cuda_pull_array(l->output_gpu, l->output, (size_t)l->batch * l->outputs);
+    }
+    net->cand_fallback = 1;
+  }
+  else if (count > 0)
+  {
+    CHECK_HIP(hipMemcpyAsync(net->cand_host, net->cand_gpu, (size_t)count * rec * sizeof(float),
+        hipMemcpyDeviceToHost, st));
+    CHECK_HIP(hipStreamSynchronize(st));
+    for (int k = 0; k < count; ++k) net->cand_order[k] = k;
+    const float* h = net->cand_host;
+    auto key = [h, rec](int k, int f) { int v; memcpy(&v, h + (size_t)k * rec + f, sizeof(int)); return v; };
+    std::sort(net->cand_order, net->cand_order + count, [&](int a, int b) {
+      if (key(a, 1) != key(b, 1)) return key(a, 1) < key(b, 1);   // image
+      if (key(a, 0) != key(b, 0)) return key(a, 0) < key(b, 0);   // layer
+      return key(a, 2) < key(b, 2);                               // anchor-major location
+    });
+  }
+  net->cand_count = (net->cand_fallback) ? 0 : count;
+  net->cand_valid = 1;
+  net->cand_seq = net->predict_seq;
+  net->cand_thresh = thresh;
+}
+
+// Detections of image b from the candidate records; dets may be NULL (count only).
+static int candidates_to_dets(Network* net, int b, float thresh, Detection* dets, int* ids, int max_dets)
+{
+  const int rec = net->cand_rec;
+  int out = 0;
+  for (int k = 0; k < net->cand_count; ++k)
+  {
+    const float* r = net->cand_host + (size_t)net->cand_order[k] * rec;
+    int tag, img, loc;
+    memcpy(&tag, r + 0, sizeof(int));
+    memcpy(&img, r + 1, sizeof(int));
+    memcpy(&loc, r + 2, sizeof(int));
+    if (img != b)
+      continue;
+    if (dets && out < max_dets)
+    {
+      const layer* l = &net->layers[tag];
+      const float* v = r + 3;
+      const int wh = l->w * l->h;
+      const int n = loc / wh, i = loc - n * wh;
+      const int col = i % l->w, row = i / l->w;
+      const int a = l->mask[n];
+      // GetYoloBox, yolo_layer.cpp:139-148 -- the same float operations as DkGetYoloDetectionsBatch
+      Box bx;
+      bx.x = (col + v[0]) / l->w;
+      bx.y = (row + v[1]) / l->h;
+      bx.w = expf(v[2]) * l->biases[2 * a] / net->w;
+      bx.h = expf(v[3]) * l->biases[2 * a + 1] / net->h;
+      const float objectness = v[4];
+      dets[out].bbox = bx;
+      dets[out].objectness = objectness;
+      dets[out].classes = l->classes;
+      for (int j = 0; j < l->classes; ++j)
+      {
+        const float prob = objectness * v[5 + j];
+        dets[out].prob[j] = (prob > thresh) ? prob : 0;
+      }
+      if (ids)
+      {
+        ids[4 * out + 0] = tag;
+        ids[4 * out + 1] = n;
+        ids[4 * out + 2] = row;
+        ids[4 * out + 3] = col;
+      }
+    }
+    ++out;
+  }
+  return out;
+}
+
+static bool heads_on_device(Network* net) { return !g_dk_pull_heads && net->gpu_index >= 0; }
+
 static int num_detections(Network* net, int b, float thresh)
 {
+  if (heads_on_device(net))
+  {
+    ensure_candidates(net, thresh);
+    if (!net->cand_fallback)
+      return candidates_to_dets(net, b, thresh, nullptr, nullptr, 0);
+  }
   int s = 0;
   for (int i = 0; i < net->n; ++i)
     if (net->layers[i].type == YOLO)
@@ -545,6 +722,11 @@ Detection* GetNetworkBoxesBatch(Network* net, int b, float thresh, int* num)
   if (b < 0 || b >= net->batch)
     error("GetNetworkBoxesBatch: batch index out of range");
   Detection* dets = make_boxes(net, b, thresh, num);
+  if (heads_on_device(net) && !net->cand_fallback)
+  {
+    candidates_to_dets(net, b, thresh, dets, nullptr, num ? *num : 0x7fffffff);
+    return dets;
+  }
   Detection* d = dets;
   for (int i = 0; i < net->n; ++i)
   {
@@ -575,6 +757,34 @@ int DkGetBoxesBatch(Network* net, int b, float thresh, float* out, int* ids, int
 {
   if (b < 0 || b >= net->batch)
     return -1;
+  if (heads_on_device(net))
+  {
+    ensure_candidates(net, thresh);
+    if (!net->cand_fallback)
+    {
+      const int num = candidates_to_dets(net, b, thresh, nullptr, nullptr, 0);
+      if (num == 0)
+        return 0;
+      const int classes = net->cand_rec - 8;
+      Detection* dets = (Detection*)xcalloc(num, sizeof(Detection));
+      for (int k = 0; k < num; ++k) dets[k].prob = (float*)xcalloc(classes, sizeof(float));
+      int* lid = (int*)xcalloc((size_t)num * 4, sizeof(int));
+      candidates_to_dets(net, b, thresh, dets, lid, num);
+      const int rec = 5 + classes;
+      for (int k = 0; k < num && k < max_dets; ++k)
+      {
+        float* o = out + (size_t)k * rec;
+        o[0] = dets[k].bbox.x; o[1] = dets[k].bbox.y; o[2] = dets[k].bbox.w; o[3] = dets[k].bbox.h;
+        o[4] = dets[k].objectness;
+        memcpy(o + 5, dets[k].prob, classes * sizeof(float));
+        if (ids)
+          memcpy(ids + (size_t)k * 4, lid + (size_t)k * 4, 4 * sizeof(int));
+      }
+      FreeDetections(dets, num);
+      free(lid);
+      return num;
+    }
+  }
   int total = 0;
   for (int i = 0; i < net->n; ++i)
   {
@@ -646,7 +856,13 @@ void FreeNetwork(Network* net)
     cuda_free(net->workspace);
     cuda_free(net->wt_scratch_gpu);
     cuda_free(net->delta_arena_gpu);
+    cuda_free(net->cand_gpu);
+    cuda_free((float*)net->cand_counter_gpu);
+    if (net->cand_host) cuda_free_host(net->cand_host);
+    if (net->u8_gpu) (void)hipFree(net->u8_gpu);
+    if (net->u8_pinned) (void)hipHostFree(net->u8_pinned);
   }
+  free(net->cand_order);
   memset(net, 0, sizeof(*net));
 }
 

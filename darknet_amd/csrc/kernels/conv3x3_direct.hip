@@ -291,10 +291,18 @@ struct PitchClass
 };
 // (row pitch, rows): sized for the feature maps of 416/512/608 nets with 64..128-pixel tiles
 // (w = 13..22 | 23..38 | 39..78 | 79..158)
+#ifndef DK_PC0
 #define DK_PC0 24, 15
+#endif
+#ifndef DK_PC1
 #define DK_PC1 40, 10
+#endif
+#ifndef DK_PC2
 #define DK_PC2 80, 8
+#endif
+#ifndef DK_PC3
 #define DK_PC3 160, 6
+#endif
 const PitchClass g_pc[4] = {{DK_PC0}, {DK_PC1}, {DK_PC2}, {DK_PC3}};
 
 struct DirectCfg

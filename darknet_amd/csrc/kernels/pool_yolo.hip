@@ -148,7 +148,87 @@ __global__ void yolo_decode_kernel(const float* __restrict__ in, float* __restri
     out[i] = v;
   }
 }
+// Candidate compaction of GetYoloDetections (src/yolo_layer.cpp:794-834): every predictor
+// whose objectness exceeds thresh appends one record {layer tag, image, loc = n*wh + i,
+// x, y, w, h, objectness, class scores (raw decoded values)} to a shared list.  The host
+// sorts the few records into the reference's scan order and applies the reference's box
+// arithmetic, so only candidates cross PCIe instead of the whole head.
+__global__ void yolo_compact_kernel(const float* __restrict__ out, size_t total, int wh, int n_anchors,
+    int entries, float thresh, int tag, float* __restrict__ records, int* __restrict__ counter, int cap)
+{
+  const int rec = 3 + entries;
+  for (size_t id = blockIdx.x * (size_t)blockDim.x + threadIdx.x; id < total;
+       id += (size_t)gridDim.x * blockDim.x)
+  {
+    const int loc = (int)(id % ((size_t)n_anchors * wh));
+    const int b = (int)(id / ((size_t)n_anchors * wh));
+    const int n = loc / wh, i = loc - n * wh;
+    const float* base = out + ((size_t)b * n_anchors + n) * entries * wh + i;
+    const float obj = base[4 * (size_t)wh];
+    if (!(obj > thresh))
+      continue;
+    const int slot = atomicAdd(counter, 1);
+    if (slot >= cap)
+      continue;  // the host sees counter > cap and falls back to the full head
+    float* r = records + (size_t)slot * rec;
+    r[0] = __int_as_float(tag);
+    r[1] = __int_as_float(b);
+    r[2] = __int_as_float(loc);
+    for (int e = 0; e < entries; ++e) r[3 + e] = base[(size_t)e * wh];
+  }
+}
+
+// Mat2Image (src/visualize.cpp:26-55): interleaved u8 rows -> planar float / 255
+__global__ void u8_hwc_to_chw_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst,
+    int w, int h, int c, size_t step, size_t image_bytes, size_t total)
+{
+  for (size_t id = blockIdx.x * (size_t)blockDim.x + threadIdx.x; id < total;
+       id += (size_t)gridDim.x * blockDim.x)
+  {
+    const int x = (int)(id % w);
+    size_t t = id / w;
+    const int y = (int)(t % h);
+    t /= h;
+    const int k = (int)(t % c);
+    const size_t b = t / c;
+    dst[id] = src[b * image_bytes + (size_t)y * step + (size_t)x * c + k] / 255.0f;
+  }
+}
 }  // namespace
+
+extern "C" int dk_yolo_compact(const float* decoded, int batch, int lw, int lh, int n_anchors,
+    int classes, float thresh, int tag, float* records, int* counter, int cap, void* stream)
+{
+  if (!decoded || !records || !counter || cap < 1)
+  {
+    fprintf(stderr, "dk_yolo_compact: invalid arguments\n");
+    return 1;
+  }
+  const size_t total = (size_t)batch * n_anchors * lw * lh;
+  if (total == 0)
+    return 0;
+  hipLaunchKernelGGL(yolo_compact_kernel, dim3(grid_for(total)), dim3(256), 0, S(stream), decoded, total,
+      lw * lh, n_anchors, classes + 5, thresh, tag, records, counter, cap);
+  CHECK_HIP(hipPeekAtLastError());
+  return 0;
+}
+
+extern "C" int dk_image_u8_to_chw(const unsigned char* hwc, float* chw, int batch, int w, int h, int c,
+    size_t row_step, void* stream)
+{
+  if (!hwc || !chw || row_step < (size_t)w * c)
+  {
+    fprintf(stderr, "dk_image_u8_to_chw: invalid arguments\n");
+    return 1;
+  }
+  const size_t total = (size_t)batch * c * h * w;
+  if (total == 0)
+    return 0;
+  hipLaunchKernelGGL(u8_hwc_to_chw_kernel, dim3(grid_for(total)), dim3(256), 0, S(stream), hwc, chw, w, h,
+      c, row_step, row_step * h, total);
+  CHECK_HIP(hipPeekAtLastError());
+  return 0;
+}
 
 extern "C" int dk_maxpool_forward(const float* x, float* y, int* indexes, int batch, int c, int h,
     int w, int size, int stride_x, int stride_y, int pad, void* stream)

@@ -55,6 +55,16 @@ class DkNet:
         assert x.size == self.batch * self.inputs
         self.L.NetworkPredict(self.p, x.ctypes.data)
 
+    def predict_u8(self, frames, row_step=None):
+        """frames: uint8 [batch, h, row_step] (interleaved HWC rows, row_step >= w*c bytes)."""
+        frames = np.ascontiguousarray(frames, np.uint8)
+        if row_step is None:
+            row_step = self.w * self.c
+        assert frames.size == self.batch * self.h * row_step
+        self.L.DkNetworkPredictU8.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        self.L.DkNetworkPredictU8.restype = None
+        self.L.DkNetworkPredictU8(self.p, frames.ctypes.data, row_step)
+
     def output(self, i):
         f = self.info(i)
         out = np.empty(f["batch"] * f["outputs"], np.float32)

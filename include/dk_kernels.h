@@ -98,6 +98,18 @@ DK_API int dk_shortcut_forward(const float* in, const float* from, float* out,
 DK_API int dk_upsample_forward(const float* in, int w, int h, int c, int batch,
     int stride, float scale, float* out, void* stream);
 
+/* Device half of GetYoloDetections (src/yolo_layer.cpp:794-834): appends one record
+ * {int tag, int image, int loc = n*w*h + i, x, y, w, h, objectness, classes...} (3 + 5 + classes
+ * floats, ints stored bitwise) per predictor with objectness > thresh to records[], counting in
+ * *counter (may exceed cap: the caller then falls back to the full head). */
+DK_API int dk_yolo_compact(const float* decoded, int batch, int lw, int lh, int n_anchors,
+    int classes, float thresh, int tag, float* records, int* counter, int cap, void* stream);
+
+/* Mat2Image (src/visualize.cpp:26-55) for `batch` interleaved u8 images of h rows of row_step bytes
+ * already in device memory: chw[b][k][y][x] = hwc[b][y*row_step + x*c + k] / 255.0f. */
+DK_API int dk_image_u8_to_chw(const unsigned char* hwc, float* chw, int batch, int w, int h, int c,
+    size_t row_step, void* stream);
+
 /* ForwardYoloLayerGpu decode, src/yolo_layer.cpp:836-853, fused into one
  * launch: copy; logistic on x,y then v*scale_x_y - 0.5*(scale_x_y-1);
  * logistic on objectness and classes; w,h raw. */

@@ -249,6 +249,17 @@ struct Network
   void* graph_exec;      /* hipGraphExec_t of the captured forward, or NULL */
   int graph_batch;
   float* wt_scratch_gpu; /* transposed weights of the layer whose data gradient is running */
+  /* device-side detection extraction and u8 input staging (see DkSetPullHeads, DkNetworkPredictU8) */
+  float* cand_gpu;       /* candidate records written by dk_yolo_compact */
+  int* cand_counter_gpu;
+  float* cand_host;      /* pinned mirror of the records */
+  int* cand_order;       /* record indices in the reference's scan order (image, layer, anchor, cell) */
+  int cand_cap, cand_count, cand_rec, cand_fallback, cand_valid;
+  long cand_seq, predict_seq;
+  float cand_thresh;
+  unsigned char* u8_gpu; /* interleaved u8 frames on the device */
+  unsigned char* u8_pinned;
+  size_t u8_bytes;
   float* delta_arena_gpu; /* train: every layer's delta_gpu lives in this one allocation (one memset per step) */
   size_t delta_arena_size;
   float* grad_bucket;    /* caller-owned contiguous gradient bucket (DkAttachGradBucket), or NULL */
@@ -375,6 +386,11 @@ LIB_API void DkNetworkInfo(Network* net, int* out /* [8]: n,batch,w,h,c,inputs,o
 LIB_API void DkLayerInfo(Network* net, int i, int* out /* [24], see tests/reflib.py INFO */);
 LIB_API float DkLayerBflops(Network* net, int i);
 LIB_API int DkLayerOutput(Network* net, int i, float* dst, size_t n); /* D2H copy of output_gpu */
+/* Mat2Image + NetworkPredict for `net->batch` interleaved u8 frames (h rows of row_step bytes each,
+ * c channels, already resized to net->w x net->h): the frames cross PCIe as bytes and are
+ * converted on the device (visualize.cpp:26-55 arithmetic).  Heads stay on the device; use
+ * GetNetworkBoxesBatch (device extraction, DkSetPullHeads(0)) or DkSetPullHeads(1). */
+LIB_API void DkNetworkPredictU8(Network* net, const unsigned char* frames_hwc, size_t row_step);
 LIB_API float* DkLayerOutputGpu(Network* net, int i);
 LIB_API float* DkLayerHostPtr(Network* net, int i, int which); /* 1 weights 2 biases 3 scales 4 mean 5 var */
 /* Flattened detections of batch item b: per det [x,y,w,h,obj,prob[classes]] and

@@ -112,6 +112,48 @@ def test_tiny_b32_config_c2(gpu, weights):
     net.close()
 
 
+def test_device_extraction_and_u8_input(gpu, weights):
+    """SURVEY 8f-1 / 8f-2.  (1) Detections extracted on the device (heads stay in HBM, only the
+    candidates cross PCIe) are bitwise the detections of the pulled-heads path, for every image
+    and for a second threshold; (2) u8 frames converted on the device (Mat2Image arithmetic)
+    give bitwise the heads of the float path; (3) the conversion kernel alone, with row padding."""
+    name, B = "yolov4-tiny", 4
+    L = gpu.lib()
+    net = netutil.DkNet(gpu, netutil.cfg_path(name), weights[name], batch=B)
+    g = np.load(os.path.join(GOLD, "net_%s.npz" % name))
+    rng = np.random.default_rng(11)
+    frames = rng.integers(0, 256, (B, net.h, net.w, net.c), dtype=np.uint8)
+    x = (frames.transpose(0, 3, 1, 2).astype(np.float32) / np.float32(255.0))
+    L.DkSetPullHeads(1)
+    net.predict(x)
+    heads = [i for i in range(net.n) if net.info(i)["type"] == O.YOLO]
+    ref_heads = [net.output(i) for i in heads]
+    t1, t2 = float(g["thresh"]), 0.5 * float(g["thresh"])
+    ref = {(b, t): net.boxes(b, t) for b in range(B) for t in (t1, t2)}
+    assert sum(len(v[0]) for v in ref.values()) > 0
+    L.DkSetPullHeads(0)
+    try:
+        net.predict_u8(frames)
+        for i, r in zip(heads, ref_heads):
+            assert np.array_equal(net.output(i), r), "u8 input path differs from the float path"
+        for (b, t), (rd, ri) in ref.items():
+            d, ids = net.boxes(b, t)
+            assert np.array_equal(ids, ri), "device extraction: detection indices differ"
+            assert np.array_equal(d, rd), "device extraction: boxes / scores differ"
+    finally:
+        L.DkSetPullHeads(1)
+    net.close()
+    # conversion kernel with padded rows
+    h, w, c, step = 5, 7, 3, 24
+    raw = rng.integers(0, 256, (2, h, step), dtype=np.uint8)
+    L.dk_image_u8_to_chw.argtypes = [gpu.C.c_void_p, gpu.C.c_void_p] + [gpu.C.c_int] * 4 + [gpu.C.c_size_t, gpu.C.c_void_p]
+    src = gpu.DeviceArray(np.frombuffer(raw.tobytes() + b"\0" * ((-raw.size) % 4), dtype=np.float32))
+    dst = gpu.DeviceArray(n=2 * c * h * w)
+    assert L.dk_image_u8_to_chw(src.ptr, dst.ptr, 2, w, h, c, step, None) == 0
+    want = raw[:, :, :w * c].reshape(2, h, w, c).transpose(0, 3, 1, 2).astype(np.float32) / np.float32(255.0)
+    assert np.array_equal(dst.numpy().reshape(2, c, h, w), want)
+
+
 def check_dets_guarded(dets, ids, odets, oids, thresh, what, guard=1e-3):
     def key(i4):
         return [tuple(r) for r in i4]
