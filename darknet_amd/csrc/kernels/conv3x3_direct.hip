@@ -80,25 +80,25 @@ conv3x3_direct_f32(const ConvArgs p)
   const int l31 = lane & 31, lh = lane >> 5;
 
   int id = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_n = id / p.tiles_m;
+  const int tile_n = fdiv(id, p.tiles_m, p.inv_tiles_m);
   const int tile_m = id - tile_n * p.tiles_m;
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
 
   const int H = p.H, W = p.W, HW = H * W, He = H + 2, K = p.K;
-  const int nbatch = p.N / HW;
+  const int nbatch = fdiv(p.N, HW, p.inv_HW);
   __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
 
   // ---- block geometry in extended rows -----------------------------------------
   int R0, rows_used;
   {
-    const int b0 = n0 / HW;
-    const int oy0 = (n0 - b0 * HW) / W;
+    const int b0 = fdiv(n0, HW, p.inv_HW);
+    const int oy0 = fdiv(n0 - b0 * HW, W, p.inv_W);
     R0 = b0 * He + oy0;  // extended row of the first pixel is R0 + 1
     const int nl = ((n0 + BN < p.N) ? n0 + BN : p.N) - 1;
-    const int bl = nl / HW;
-    const int oyl = (nl - bl * HW) / W;
+    const int bl = fdiv(nl, HW, p.inv_HW);
+    const int oyl = fdiv(nl - bl * HW, W, p.inv_W);
     rows_used = bl * He + oyl + 1 - R0 + 2;
   }
   const int used_slots = rows_used * P;
@@ -111,9 +111,9 @@ conv3x3_direct_f32(const ConvArgs p)
   {
     int n = n0 + wn * WN + j * 32 + l31;
     n = (n < p.N) ? n : p.N - 1;
-    const int b = n / HW;
+    const int b = fdiv(n, HW, p.inv_HW);
     const int q = n - b * HW;
-    const int oy = q / W;
+    const int oy = fdiv(q, W, p.inv_W);
     const int ox = q - oy * W;
     const int lpos = (b * He + oy - R0) * P + ox;
     lb[j][0] = lpos + lh * D1;
@@ -130,7 +130,7 @@ conv3x3_direct_f32(const ConvArgs p)
     const int r = i / P;
     const int col = i - r * P - 1;
     const int Rr = R0 + r;
-    const int b = Rr / He;
+    const int b = fdiv(Rr, He, p.inv_He);
     const int ye = Rr - b * He - 1;
     const bool ok = i < used_slots && (unsigned)col < (unsigned)W && (unsigned)ye < (unsigned)H && b < nbatch;
     gofs[jj] = ok ? (unsigned)((b * p.Ctot * H + ye) * W + col) * 4u : OOB;
@@ -391,6 +391,7 @@ int dk_conv_direct_launch(ConvArgs a, int dcfg, hipStream_t st)
     CHECK_HIP(hipFuncSetAttribute((const void*)c.kernel[pc], hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     attr_set[dcfg][pc] = true;
   }
+  conv_args_finish(a);
   const long long nblk = (long long)a.tiles_m * a.tiles_n;
   hipLaunchKernelGGL(c.kernel[pc], dim3((unsigned)nblk), dim3((c.bm / c.wm) * (c.bn / c.wn) * 64),
       bytes, st, a);

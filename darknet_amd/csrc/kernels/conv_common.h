@@ -33,7 +33,32 @@ struct ConvArgs
   int act;
   int tiles_m, tiles_n, groups;
   int mode;          // 0 forward gather; 1 data-gradient gather (x = delta, H/W = delta dims, OH/OW = input dims)
+  // reciprocals of the divisors the kernels' index arithmetic uses (set by conv_args_finish):
+  // an integer division costs ~40 VALU instructions, fdiv() four
+  double inv_OHW, inv_OW, inv_tiles_m, inv_per_group, inv_HW, inv_W, inv_He;
 };
+
+// exact floor(n / d) for 0 <= n < 2^31, d > 0, given inv = 1.0 / d: the double estimate is within
+// one of the quotient, one correction step makes it exact
+__device__ __forceinline__ int fdiv(int n, int d, double inv)
+{
+  int q = (int)(((double)n + 0.5) * inv);
+  const int r = n - q * d;
+  q += (r >= d) - (r < 0);
+  return q;
+}
+
+inline void conv_args_finish(ConvArgs& a)
+{
+  a.inv_OHW = 1.0 / (a.OHW > 0 ? a.OHW : 1);
+  a.inv_OW = 1.0 / (a.OW > 0 ? a.OW : 1);
+  a.inv_tiles_m = 1.0 / (a.tiles_m > 0 ? a.tiles_m : 1);
+  const long long pg = (long long)a.tiles_m * a.tiles_n;
+  a.inv_per_group = 1.0 / (pg > 0 ? (double)pg : 1.0);
+  a.inv_HW = 1.0 / ((double)a.H * a.W > 0 ? (double)a.H * a.W : 1.0);
+  a.inv_W = 1.0 / (a.W > 0 ? a.W : 1);
+  a.inv_He = 1.0 / (a.H + 2);
+}
 
 __device__ __forceinline__ float ld_buf(__amdgpu_buffer_rsrc_t r, unsigned byte_off)
 {
@@ -84,7 +109,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
     const int n = n0 + wn * WN + j * 32 + l31;
     const bool nv = n < p.N;
     const int nn = nv ? n : 0;
-    const int b = nn / p.OHW;
+    const int b = fdiv(nn, p.OHW, p.inv_OHW);
     const int pix = nn - b * p.OHW;
     obase[j] = nv ? (unsigned)((b * p.Mtot + g * p.M) * p.OHW + pix) * 4u : 0xFFFFFFFFu;
   }

@@ -90,9 +90,9 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
   // ---- which tile -------------------------------------------------------
   const int per_group = p.tiles_m * p.tiles_n;
   int id = xcd_remap(blockIdx.x, gridDim.x);
-  const int g = id / per_group;
+  const int g = fdiv(id, per_group, p.inv_per_group);
   id -= g * per_group;
-  const int tile_n = id / p.tiles_m;
+  const int tile_n = fdiv(id, p.tiles_m, p.inv_tiles_m);
   const int tile_m = id - tile_n * p.tiles_m;
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
@@ -116,7 +116,7 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
     const int n = n0 + bq * 4;
     if (n < p.N)
     {
-      const int b = n / p.OHW;
+      const int b = fdiv(n, p.OHW, p.inv_OHW);
       const int pix = n - b * p.OHW;
       bv_base = (unsigned)((b * p.Ctot + g * p.C) * HW + pix) * 4u;
     }
@@ -126,9 +126,9 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
     const int n = n0 + bn_l;
     const bool nv = n < p.N;
     const int nn = nv ? n : 0;
-    const int b = nn / p.OHW;
+    const int b = fdiv(nn, p.OHW, p.inv_OHW);
     const int pix = nn - b * p.OHW;
-    const int oy = pix / p.OW;
+    const int oy = fdiv(pix, p.OW, p.inv_OW);
     const int ox = pix - oy * p.OW;
     if (p.mode == 0)
     {
@@ -751,6 +751,7 @@ int dk_conv_forward_cfg(const DkConvDesc* d, const float* x, const float* weight
     a.tiles_n = (a.N + c.bn - 1) / c.bn;
     a.groups = d->groups;
     a.mode = 0;
+    conv_args_finish(a);
     const long long nblk = (long long)a.tiles_m * a.tiles_n * d->groups;
     if (nblk > 0x7fffffffLL)
     {
@@ -850,6 +851,7 @@ extern "C" int dk_conv_backward_data(const DkConvDesc* d, const float* delta, co
     a.groups = d->groups;
     const long long nblk = (long long)a.tiles_m * a.tiles_n * d->groups;
     const bool avec = (K % 4 == 0) && (((uintptr_t)wt & 15) == 0);
+    conv_args_finish(a);
     hipLaunchKernelGGL(c.kernel[avec ? 1 : 0], dim3((unsigned)nblk), dim3(c.threads), 0, st, a);
     CHECK_HIP(hipPeekAtLastError());
   }

@@ -55,9 +55,9 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
 
   const int per_group = p.tiles_m * p.tiles_n;
   int id = xcd_remap(blockIdx.x, gridDim.x);
-  const int g = id / per_group;
+  const int g = fdiv(id, per_group, p.inv_per_group);
   id -= g * per_group;
-  const int tile_n = id / p.tiles_m;
+  const int tile_n = fdiv(id, p.tiles_m, p.inv_tiles_m);
   const int tile_m = id - tile_n * p.tiles_m;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -75,9 +75,9 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
     const int n = n0 + bn_l;
     const bool nv = n < p.N;
     const int nn = nv ? n : 0;
-    const int b = nn / p.OHW;
+    const int b = fdiv(nn, p.OHW, p.inv_OHW);
     const int pix = nn - b * p.OHW;
-    const int oy = pix / p.OW, ox = pix - oy * p.OW;
+    const int oy = fdiv(pix, p.OW, p.inv_OW), ox = pix - oy * p.OW;
     const int iy0 = oy * p.stride_y - p.pad, ix0 = ox * p.stride_x - p.pad;
     xbase4 = (unsigned)((b * p.Ctot + g * p.C) * HW + iy0 * p.W + ix0) * 4u;
     if (nv)
@@ -275,6 +275,7 @@ int dk_conv_forward_half_strided(const DkConvDesc* d, const float* x, const floa
     a.tiles_m = (M + bm - 1) / bm;
     a.tiles_n = (a.N + bn - 1) / bn;
     const long long nblk = (long long)a.tiles_m * a.tiles_n;
+    conv_args_finish(a);
     if (small_m)
       hipLaunchKernelGGL((conv_igemm_f16<64, 128, 32, 64>), dim3((unsigned)nblk), dim3(256), 0, st, a);
     else
