@@ -79,9 +79,9 @@ conv3x3_direct_f32(const ConvArgs p)
   const int wm = wave / NWN, wn = wave % NWN;
   const int l31 = lane & 31, lh = lane >> 5;
 
-  int id = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_n = fdiv(id, p.tiles_m, p.inv_tiles_m);
-  const int tile_m = id - tile_n * p.tiles_m;
+  int g_unused, tile_m, tile_n;
+  if (!conv_block_tile(p, g_unused, tile_m, tile_n))
+    return;
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
 
@@ -391,8 +391,9 @@ int dk_conv_direct_launch(ConvArgs a, int dcfg, hipStream_t st)
     CHECK_HIP(hipFuncSetAttribute((const void*)c.kernel[pc], hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     attr_set[dcfg][pc] = true;
   }
+  a.groups = 1;
   conv_args_finish(a);
-  const long long nblk = (long long)a.tiles_m * a.tiles_n;
+  const long long nblk = conv_pick_partition(a, (size_t)a.M * a.K * sizeof(float), c.bm);
   hipLaunchKernelGGL(c.kernel[pc], dim3((unsigned)nblk), dim3((c.bm / c.wm) * (c.bn / c.wn) * 64),
       bytes, st, a);
   return pc;

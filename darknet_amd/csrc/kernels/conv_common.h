@@ -36,6 +36,10 @@ struct ConvArgs
   // reciprocals of the divisors the kernels' index arithmetic uses (set by conv_args_finish):
   // an integer division costs ~40 VALU instructions, fdiv() four
   double inv_OHW, inv_OW, inv_tiles_m, inv_per_group, inv_HW, inv_W, inv_He;
+  // XCD partition (conv_pick_partition): pm x (8/pm) grid of XCDs over (M tiles x N tiles);
+  // pm = 1 is the N-major default (xcd_remap)
+  int pm, tm_per, tn_per;
+  double inv_tm_per;
 };
 
 // exact floor(n / d) for 0 <= n < 2^31, d > 0, given inv = 1.0 / d: the double estimate is within
@@ -46,6 +50,67 @@ __device__ __forceinline__ int fdiv(int n, int d, double inv)
   const int r = n - q * d;
   q += (r >= d) - (r < 0);
   return q;
+}
+
+// Bijective XCD remap (8 XCDs, blocks dealt round-robin): block `bid` of `nwg`
+// gets a logical id such that ids handled by one XCD are contiguous.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg)
+{
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+// Which tile does this workgroup compute?  Default: logical ids dealt so that one XCD gets
+// a contiguous N range with all its M tiles (the M tiles of a pixel tile share the input in
+// that XCD's L2).  When the weights do not fit an L2 (4 MB) that order re-streams them for
+// every pixel tile, so the host switches to a pm x (8/pm) partition: each XCD owns 1/pm of
+// the filters (a slice that fits its L2) and 1/(8/pm) of the pixels.  Returns false for the
+// surplus workgroups of a partition that does not divide evenly.
+__device__ __forceinline__ bool conv_block_tile(const ConvArgs& p, int& g, int& tile_m, int& tile_n)
+{
+  if (p.pm > 1)
+  {
+    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+    const int xm = xcd & (p.pm - 1), xn = xcd / p.pm;
+    const int tnl = fdiv(li, p.tm_per, p.inv_tm_per);
+    const int tml = li - tnl * p.tm_per;
+    g = 0;
+    tile_m = xm * p.tm_per + tml;
+    tile_n = xn * p.tn_per + tnl;
+    return tile_m < p.tiles_m && tile_n < p.tiles_n;
+  }
+  const int per_group = p.tiles_m * p.tiles_n;
+  int id = xcd_remap(blockIdx.x, gridDim.x);
+  g = fdiv(id, per_group, p.inv_per_group);
+  id -= g * per_group;
+  tile_n = fdiv(id, p.tiles_m, p.inv_tiles_m);
+  tile_m = id - tile_n * p.tiles_m;
+  return true;
+}
+
+// Host: choose the XCD partition for a launch whose tiles_m / tiles_n are set; returns the grid size.
+inline long long conv_pick_partition(ConvArgs& a, size_t weight_bytes, int tile_rows)
+{
+  a.pm = 1;
+  a.tm_per = a.tiles_m;
+  a.tn_per = a.tiles_n;
+  const size_t l2_budget = (size_t)3 << 20;  // of the 4 MB per XCD, leave room for the input stream
+  if (a.groups == 1 && weight_bytes > l2_budget)
+  {
+    int pm = 1;
+    while (pm < 8 && pm * 2 <= a.tiles_m && weight_bytes / pm > l2_budget) pm *= 2;
+    if (pm > 1)
+    {
+      a.pm = pm;
+      a.tm_per = (a.tiles_m + pm - 1) / pm;
+      a.tn_per = (a.tiles_n + (8 / pm) - 1) / (8 / pm);
+    }
+  }
+  (void)tile_rows;
+  a.inv_tm_per = 1.0 / (a.tm_per > 0 ? a.tm_per : 1);
+  return a.pm > 1 ? 8LL * a.tm_per * a.tn_per : (long long)a.tiles_m * a.tiles_n * a.groups;
 }
 
 inline void conv_args_finish(ConvArgs& a)
@@ -71,16 +136,6 @@ __device__ __forceinline__ float4 ld_buf4(__amdgpu_buffer_rsrc_t r, unsigned byt
   u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
       __uint_as_float(v.w));
-}
-
-// Bijective XCD remap (8 XCDs, blocks dealt round-robin): block `bid` of `nwg`
-// gets a logical id such that ids handled by one XCD are contiguous.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg)
-{
-  const int q = nwg >> 3, r = nwg & 7;
-  const int xcd = bid & 7;
-  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  return base + (bid >> 3);
 }
 
 constexpr unsigned OOB = 0x80000000u;  // ORed into a byte offset: always outside the buffer

@@ -88,12 +88,9 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
   const int wm = wave / NWN, wn = wave % NWN;
 
   // ---- which tile -------------------------------------------------------
-  const int per_group = p.tiles_m * p.tiles_n;
-  int id = xcd_remap(blockIdx.x, gridDim.x);
-  const int g = fdiv(id, per_group, p.inv_per_group);
-  id -= g * per_group;
-  const int tile_n = fdiv(id, p.tiles_m, p.inv_tiles_m);
-  const int tile_m = id - tile_n * p.tiles_m;
+  int g, tile_m, tile_n;
+  if (!conv_block_tile(p, g, tile_m, tile_n))
+    return;
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
 
@@ -752,7 +749,7 @@ int dk_conv_forward_cfg(const DkConvDesc* d, const float* x, const float* weight
     a.groups = d->groups;
     a.mode = 0;
     conv_args_finish(a);
-    const long long nblk = (long long)a.tiles_m * a.tiles_n * d->groups;
+    const long long nblk = conv_pick_partition(a, (size_t)M * K * sizeof(float), c.bm);
     if (nblk > 0x7fffffffLL)
     {
       fprintf(stderr, "dk_conv_forward: grid too large\n");
@@ -849,7 +846,7 @@ extern "C" int dk_conv_backward_data(const DkConvDesc* d, const float* delta, co
     a.tiles_m = (Cg + c.bm - 1) / c.bm;
     a.tiles_n = (a.N + c.bn - 1) / c.bn;
     a.groups = d->groups;
-    const long long nblk = (long long)a.tiles_m * a.tiles_n * d->groups;
+    const long long nblk = conv_pick_partition(a, (size_t)a.M * a.K * sizeof(float), c.bm);
     const bool avec = (K % 4 == 0) && (((uintptr_t)wt & 15) == 0);
     conv_args_finish(a);
     hipLaunchKernelGGL(c.kernel[avec ? 1 : 0], dim3((unsigned)nblk), dim3(c.threads), 0, st, a);

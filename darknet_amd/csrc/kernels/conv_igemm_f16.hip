@@ -53,12 +53,9 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
   const int wm = wave / NWN, wn = wave % NWN;
   const int l31 = lane & 31, lh = lane >> 5;
 
-  const int per_group = p.tiles_m * p.tiles_n;
-  int id = xcd_remap(blockIdx.x, gridDim.x);
-  const int g = fdiv(id, per_group, p.inv_per_group);
-  id -= g * per_group;
-  const int tile_n = fdiv(id, p.tiles_m, p.inv_tiles_m);
-  const int tile_m = id - tile_n * p.tiles_m;
+  int g, tile_m, tile_n;
+  if (!conv_block_tile(p, g, tile_m, tile_n))
+    return;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const int HW = p.H * p.W;
@@ -274,8 +271,8 @@ int dk_conv_forward_half_strided(const DkConvDesc* d, const float* x, const floa
     const int bm = small_m ? 64 : 128, bn = 128;
     a.tiles_m = (M + bm - 1) / bm;
     a.tiles_n = (a.N + bn - 1) / bn;
-    const long long nblk = (long long)a.tiles_m * a.tiles_n;
     conv_args_finish(a);
+    const long long nblk = conv_pick_partition(a, (size_t)M * K * sizeof(float), bm);
     if (small_m)
       hipLaunchKernelGGL((conv_igemm_f16<64, 128, 32, 64>), dim3((unsigned)nblk), dim3(256), 0, st, a);
     else
