@@ -106,6 +106,28 @@ def test_conv_direct3x3_vs_oracle(gpu, case):
     L.dk_conv_force_config(-1)
 
 
+@pytest.mark.parametrize("case", [(48, 32, 608, 608, 8, 2), (364, 64, 152, 152, 8, 1)])
+def test_conv_batch_chunking_beyond_2gib(gpu, case):
+    """Maximum sizes: the kernels address one launch with 32-bit byte offsets, so inputs of 2^29
+    elements or more are processed in batch chunks (gather kernel: stride 2; patch-in-LDS kernel:
+    stride 1).  Size-independent check: the batch repeats 3 distinct images, so every item must
+    equal the item of a 3-image run through the same kernels, bit for bit."""
+    B, c, h, w, n, stride = case
+    assert B * c * h * w >= 2 ** 29
+    rng = np.random.default_rng(5)
+    x3 = rng.uniform(-1, 1, (3, c, h, w)).astype(np.float32)
+    wt = (rng.uniform(-1, 1, (n, c, 3, 3)) * 0.06).astype(np.float32)
+    bias = rng.uniform(-.5, .5, n).astype(np.float32)
+    y3 = gpu.conv_forward(x3, wt, bias, 3, c, h, w, n, 3, stride, 1, O.LEAKY)
+    ref3, _ = orc_conv(x3[:1], wt, bias, 1, c, h, w, n, 3, stride, 1, O.LEAKY)
+    util.assert_close(y3[:1], ref3, "3-image run vs oracle")
+    x = np.tile(x3, (B // 3 + 1, 1, 1, 1))[:B]
+    y = gpu.conv_forward(x, wt, bias, B, c, h, w, n, 3, stride, 1, O.LEAKY)
+    del x
+    for b in range(B):
+        assert np.array_equal(y[b], y3[b % 3]), "item %d of the chunked batch differs" % b
+
+
 def test_conv_identity_asymmetric(gpu):
     """A = I check with an asymmetric B: catches a transposed C/D fragment map."""
     c = n = 64
