@@ -44,7 +44,7 @@ struct ConvArgs
 
 // exact floor(n / d) for 0 <= n < 2^31, d > 0, given inv = 1.0 / d: the double estimate is within
 // one of the quotient, one correction step makes it exact
-__device__ __forceinline__ int fdiv(int n, int d, double inv)
+__host__ __device__ __forceinline__ int fdiv(int n, int d, double inv)
 {
   int q = (int)(((double)n + 0.5) * inv);
   const int r = n - q * d;
@@ -54,7 +54,7 @@ __device__ __forceinline__ int fdiv(int n, int d, double inv)
 
 // Bijective XCD remap (8 XCDs, blocks dealt round-robin): block `bid` of `nwg`
 // gets a logical id such that ids handled by one XCD are contiguous.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg)
+__host__ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 {
   const int q = nwg >> 3, r = nwg & 7;
   const int xcd = bid & 7;
@@ -68,11 +68,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 // every pixel tile, so the host switches to a pm x (8/pm) partition: each XCD owns 1/pm of
 // the filters (a slice that fits its L2) and 1/(8/pm) of the pixels.  Returns false for the
 // surplus workgroups of a partition that does not divide evenly.
-__device__ __forceinline__ bool conv_block_tile(const ConvArgs& p, int& g, int& tile_m, int& tile_n)
+// (bid, nblk) = (blockIdx.x, gridDim.x); host-callable so that the mapping is unit-tested on the CPU
+__host__ __device__ __forceinline__ bool conv_block_tile_of(const ConvArgs& p, int bid, int nblk, int& g,
+    int& tile_m, int& tile_n)
 {
   if (p.pm > 1)
   {
-    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+    const int xcd = bid & 7, li = bid >> 3;
     const int xm = xcd & (p.pm - 1), xn = xcd / p.pm;
     const int tnl = fdiv(li, p.tm_per, p.inv_tm_per);
     const int tml = li - tnl * p.tm_per;
@@ -82,12 +84,17 @@ __device__ __forceinline__ bool conv_block_tile(const ConvArgs& p, int& g, int& 
     return tile_m < p.tiles_m && tile_n < p.tiles_n;
   }
   const int per_group = p.tiles_m * p.tiles_n;
-  int id = xcd_remap(blockIdx.x, gridDim.x);
+  int id = xcd_remap(bid, nblk);
   g = fdiv(id, per_group, p.inv_per_group);
   id -= g * per_group;
   tile_n = fdiv(id, p.tiles_m, p.inv_tiles_m);
   tile_m = id - tile_n * p.tiles_m;
   return true;
+}
+
+__device__ __forceinline__ bool conv_block_tile(const ConvArgs& p, int& g, int& tile_m, int& tile_n)
+{
+  return conv_block_tile_of(p, (int)blockIdx.x, (int)gridDim.x, g, tile_m, tile_n);
 }
 
 // Host: choose the XCD partition for a launch whose tiles_m / tiles_n are set; returns the grid size.

@@ -615,6 +615,26 @@ extern "C" __attribute__((visibility("default"))) const char* dk_conv_kernel_nam
   return buf;
 }
 
+// ---- CPU-testable host logic (tests/test_host_cpu.py) ---------------------------------
+// exact reciprocal division used by the kernels' index arithmetic
+extern "C" __attribute__((visibility("default"))) int DkTestFdiv(int n, int d) { return fdiv(n, d, 1.0 / d); }
+
+// Tile of workgroup `bid` under the XCD partition the host would pick for (tiles_m, tiles_n, groups,
+// weight_bytes): out = {grid size, pm, valid, g, tile_m, tile_n}
+extern "C" __attribute__((visibility("default"))) void DkTestBlockTile(int tiles_m, int tiles_n, int groups,
+    long long weight_bytes, int bid, int* out)
+{
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.tiles_m = tiles_m; a.tiles_n = tiles_n; a.groups = groups;
+  a.OHW = a.OW = a.H = a.W = 1;
+  conv_args_finish(a);
+  const long long nblk = conv_pick_partition(a, (size_t)weight_bytes, 64);
+  int g = 0, tm = 0, tn = 0;
+  const bool ok = bid < nblk && conv_block_tile_of(a, bid, (int)nblk, g, tm, tn);
+  out[0] = (int)nblk; out[1] = a.pm; out[2] = ok; out[3] = g; out[4] = tm; out[5] = tn;
+}
+
 int dk_conv_num_configs() { return g_ncfg + dk_conv_direct_num_configs(); }
 
 const int2* dk_conv_ktab(const DkConvDesc* d, int K, int C, int mode) { return get_plan(d, K, C, mode).ktab; }

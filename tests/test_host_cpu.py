@@ -160,3 +160,40 @@ def test_synth_is_deterministic_and_matches_scalar_lcg():
         ref.append((s >> 8) / 16777216.0)
     assert np.array_equal(v, np.array(ref, np.float32))
     assert np.array_equal(synth.make_input(2, 3, 8, 8), synth.make_input(2, 3, 8, 8))
+
+
+def test_kernel_index_arithmetic_on_host(dk):
+    """Host-callable halves of the kernels' index logic: (1) the reciprocal division is exact;
+    (2) under every XCD partition the host can pick, the workgroup -> tile map covers each
+    (group, M tile, N tile) exactly once (surplus workgroups are flagged invalid)."""
+    import ctypes as C
+    L = dk.lib()
+    L.DkTestFdiv.argtypes = [C.c_int, C.c_int]
+    L.DkTestFdiv.restype = C.c_int
+    rng = np.random.default_rng(3)
+    ds = [1, 2, 3, 7, 9, 19, 361, 1444, 5776, 23104, 92416, 369664, 1048573, (1 << 20) + 7]
+    for d in ds:
+        ns = np.concatenate([np.arange(0, 5 * d, max(1, d // 7)), [d - 1, d, d + 1, 2 ** 31 - 1, 2 ** 30, 2 ** 29 - 1],
+                             rng.integers(0, 2 ** 31 - 1, 200), (np.arange(1, 40) * d - 1), np.arange(1, 40) * d])
+        for n in ns:
+            n = int(min(n, 2 ** 31 - 1))
+            assert L.DkTestFdiv(n, d) == n // d, (n, d)
+    L.DkTestBlockTile.argtypes = [C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_int, C.POINTER(C.c_int)]
+    out = (C.c_int * 6)()
+    seen_pm = set()
+    for tiles_m, tiles_n, groups, wbytes in [(8, 181, 1, 4718592), (16, 46, 1, 18874368), (8, 91, 1, 9437184),
+                                             (4, 181, 1, 2359296), (3, 17, 1, 40 << 20), (1, 5, 1, 64 << 20),
+                                             (2, 7, 2, 64 << 20), (16, 1, 1, 50 << 20), (5, 3, 1, 7 << 20)]:
+        L.DkTestBlockTile(tiles_m, tiles_n, groups, wbytes, 0, out)
+        nblk, pm = out[0], out[1]
+        seen_pm.add(pm)
+        assert pm in (1, 2, 4, 8) and pm <= max(1, tiles_m)
+        count = {}
+        for bid in range(nblk):
+            L.DkTestBlockTile(tiles_m, tiles_n, groups, wbytes, bid, out)
+            if out[2]:
+                key = (out[3], out[4], out[5])
+                assert 0 <= out[3] < groups and 0 <= out[4] < tiles_m and 0 <= out[5] < tiles_n
+                count[key] = count.get(key, 0) + 1
+        assert len(count) == groups * tiles_m * tiles_n and set(count.values()) == {1}, (tiles_m, tiles_n, pm)
+    assert {1, 2, 8} <= seen_pm
