@@ -286,12 +286,12 @@ static void DkYoloLossJoin(layer* l)
       hipMemcpyHostToDevice, get_cuda_stream()));
 }
 
-void BackwardNetworkGpu(Network* net, NetworkState state)
+static void backward_range(Network* net, NetworkState state, int hi, int lo)
 {
   state.workspace = net->workspace;
   float* original_input = state.input;
   float* original_delta = state.delta;
-  for (int i = net->n - 1; i >= 0; --i)
+  for (int i = hi - 1; i >= lo; --i)
   {
     state.index = i;
     layer* l = &net->layers[i];
@@ -317,6 +317,10 @@ void BackwardNetworkGpu(Network* net, NetworkState state)
   }
 }
 
+void BackwardNetworkGpu(Network* net, NetworkState state) { backward_range(net, state, net->n, 0); }
+
+extern "C" LIB_API size_t DkGradBucketSize(Network* net);
+
 void UpdateNetworkGpu(Network* net)
 {
   cuda_set_device(net->gpu_index);
@@ -333,6 +337,11 @@ void UpdateNetworkGpu(Network* net)
     if (l->update_gpu && l->dont_update < iter)
       l->update_gpu(l, actual_batch, lr, net->momentum, net->decay, net->loss_scale);
   }
+  // data parallel: the bucket now holds momentum * (summed gradients), identical on every
+  // replica; keep 1/R of it so that the next all-reduce (a sum over R replicas) restores it
+  // exactly once -- the single-process accumulation over subdivisions does the same implicitly
+  if (net->grad_replicas > 1 && net->grad_bucket)
+    dk_scal(DkGradBucketSize(net), 1.0f / net->grad_replicas, net->grad_bucket, get_cuda_stream());
 }
 
 void UpdateNetwork(Network* net) { UpdateNetworkGpu(net); }
@@ -366,6 +375,52 @@ void ForwardBackwardNetworkGpu(Network* net, float* x, float* y)
     fprintf(stderr, "[train timing] input %.2f ms, forward issue %.2f, backward issue (+ loss joins) %.2f, drain %.2f\n",
         t1 - t0, t2 - t1, t3 - t2, now_ms() - t3);
   }
+}
+
+// ---- split train step (overlapped all-reduce, darknet_amd/train_dist.py) -----------------
+static NetworkState train_state(Network* net)
+{
+  NetworkState state;
+  memset(&state, 0, sizeof(state));
+  state.net = net;
+  state.input = net->input_state_gpu;
+  state.train = 1;
+  return state;
+}
+
+void DkTrainForward(Network* net, float* x, float* y)
+{
+  net->truth = y;
+  if (net->gpu_index < 0 || !net->train)
+    error("DkTrainForward: needs a train-mode network on a HIP device");
+  net->seen += net->batch;
+  const size_t x_size = (size_t)GetNetworkInputSize(net) * net->batch;
+  memcpy(net->input_pinned_cpu, x, x_size * sizeof(float));
+  cuda_push_array(net->input_state_gpu, net->input_pinned_cpu, x_size);
+  ForwardNetworkGpu(net, train_state(net));
+}
+
+void DkBackwardRange(Network* net, int hi, int lo)
+{
+  if (hi > net->n) hi = net->n;
+  if (lo < 0) lo = 0;
+  backward_range(net, train_state(net), hi, lo);
+}
+
+float DkTrainFinish(Network* net)
+{
+  for (int i = 0; i < net->n; ++i)
+    if (net->layers[i].type == YOLO)
+      DkYoloLossJoin(&net->layers[i]);
+  float sum = 0;
+  int count = 0;
+  for (int i = 0; i < net->n; ++i)
+    if (net->layers[i].cost)
+    {
+      sum += net->layers[i].cost[0];
+      ++count;
+    }
+  return count ? sum / count : 0;
 }
 
 float TrainNetworkDatumGpu(Network* net, float* x, float* y)
@@ -470,4 +525,20 @@ extern "C" LIB_API void DkAttachGradBucket(Network* net, float* bucket)
 // (each replica contributes one sub-batch, exactly the reference's accumulation
 // over subdivisions).
 extern "C" LIB_API void DkSetSubdivisions(Network* net, int subdiv) { net->subdiv = subdiv; }
+extern "C" LIB_API void DkSetReplicas(Network* net, int replicas)
+{
+  net->subdiv = replicas;
+  net->grad_replicas = replicas;
+}
+extern "C" LIB_API size_t DkGradBucketOffset(Network* net, int upto)
+{
+  size_t n = 0;
+  for (int i = 0; i < net->n && i < upto; ++i)
+  {
+    layer* l = &net->layers[i];
+    if (l->type == CONVOLUTIONAL && l->weight_updates_gpu)
+      n += (size_t)l->nweights + l->n + (l->scale_updates_gpu ? l->n : 0);
+  }
+  return n;
+}
 extern "C" LIB_API void DkAdvanceIteration(Network* net) { net->curr_iter++; }

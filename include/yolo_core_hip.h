@@ -263,6 +263,7 @@ struct Network
   float* delta_arena_gpu; /* train: every layer's delta_gpu lives in this one allocation (one memset per step) */
   size_t delta_arena_size;
   float* grad_bucket;    /* caller-owned contiguous gradient bucket (DkAttachGradBucket), or NULL */
+  int grad_replicas;     /* data-parallel replicas whose buckets are summed before the update (DkSetReplicas) */
 };
 
 #ifdef __cplusplus
@@ -332,6 +333,19 @@ LIB_API void DkSetMaxIter(Network* net, int max_iter);
 LIB_API size_t DkGradBucketSize(Network* net);
 LIB_API void DkAttachGradBucket(Network* net, float* bucket);
 LIB_API void DkSetSubdivisions(Network* net, int subdiv);
+/* R data-parallel replicas (one process per GPU) whose gradient buckets are all-reduced (summed)
+ * between the backward pass and UpdateNetworkGpu: B = batch x R in the update, and the momentum
+ * carry-over that UpdateNetworkGpu leaves in the bucket is kept as 1/R per replica, so that the
+ * next all-reduce restores it exactly once. */
+LIB_API void DkSetReplicas(Network* net, int replicas);
+/* Split train step for overlapping the bucket all-reduce with the backward pass:
+ * DkTrainForward (input push, forward, host losses started), DkBackwardRange(net, hi, lo) =
+ * backward of layers hi-1 ... lo, DkTrainFinish = joins, returns the cost.  DkGradBucketOffset(net, i)
+ * = offset (floats) of layer i's first gradient in the bucket (or of the next conv above it). */
+LIB_API void DkTrainForward(Network* net, float* x, float* y);
+LIB_API void DkBackwardRange(Network* net, int hi, int lo);
+LIB_API float DkTrainFinish(Network* net);
+LIB_API size_t DkGradBucketOffset(Network* net, int upto_layer);
 LIB_API void DkAdvanceIteration(Network* net);
 /* D2H copy of a layer tensor: which = 6 delta, 7 weight_updates, 8 bias_updates,
  * 9 scale_updates, 1 weights, 2 biases, 3 scales, 4 rolling_mean, 5 rolling_variance,
