@@ -317,12 +317,11 @@ struct BnRecompute
   float xn, d;  // x_norm, delta * activation gradient
 };
 
-__device__ __forceinline__ BnRecompute bn_recompute(float x, float delta, float mean, float inv_fwd,
+__device__ __forceinline__ BnRecompute bn_recompute(float x, float delta, float mean, float div_fwd,
     float scale, float bias, int act)
 {
   BnRecompute r;
-  (void)inv_fwd;
-  r.xn = (x - mean) / inv_fwd;  // inv_fwd = sqrtf(variance + 1e-6f): the forward's divisor
+  r.xn = (x - mean) / div_fwd;  // div_fwd = sqrtf(variance + 1e-6f): the forward's divisor
   float a = r.xn * scale;
   a = a + bias;
   float g;

@@ -12,7 +12,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import darknet_amd as dk  # noqa: E402
-from oracle import orc_net as O  # noqa: E402  (shape parsing only; dev tool)
+from darknet_amd import netapi  # noqa: E402
 
 
 def main():
@@ -20,20 +20,32 @@ def main():
     iters = int(sys.argv[3]) if len(sys.argv) > 3 else 5
     L = dk.lib()
     L.cuda_set_device(0)
-    net = O.parse_cfg(cfg, batch=batch)
+    # layer table from the product's own parser (no device work)
+    p = L.DkNetworkCreate()
+    L.ParseNetworkCfg.restype = C.c_bool
+    L.ParseNetworkCfg.argtypes = [C.c_void_p, C.c_char_p, C.c_bool]
+    assert L.ParseNetworkCfg(p, cfg.encode(), False)
+    a = (C.c_int * 8)()
+    L.DkNetworkInfo(p, a)
     shapes = {}
-    for l in net.layers:
-        if l.type != O.CONVOLUTIONAL:
+    outputs = []
+    for i in range(a[0]):
+        f = (C.c_int * 24)()
+        L.DkLayerInfo(p, i, f)
+        f = dict(zip(netapi.INFO, list(f)))
+        if f["type"] != 0:   # CONVOLUTIONAL
             continue
-        key = (l.c, l.h, l.w, l.n, l.size, l.stride_x, l.pad, l.activation, l.groups)
-        shapes.setdefault(key, []).append(l.index)
+        outputs.append(f["outputs"])
+        key = (f["c"], f["h"], f["w"], f["n"], f["size"], f["stride_x"], f["pad"], f["activation"], f["groups"])
+        shapes.setdefault(key, []).append(i)
+    L.DkNetworkDestroy(p)
     ncfg = L.dk_conv_force_config(-1)
     names = [L.dk_conv_config_name(i).decode() for i in range(ncfg)]
     rows = []
     tot_best = tot_heur = 0.0
     tot_gflop = 0.0
     maxin = max(batch * k[0] * k[1] * k[2] for k in shapes)
-    maxout = max(batch * l.outputs for l in net.layers if l.type == O.CONVOLUTIONAL)
+    maxout = max(batch * o for o in outputs)
     rng = np.random.default_rng(0)
     dx = dk.DeviceArray(rng.uniform(-1, 1, maxin).astype(np.float32))
     dy = dk.DeviceArray(n=maxout)
