@@ -156,7 +156,7 @@ def main():
         net.predict_u8(frames)
         n = 0
         for b in range(args.batch):
-            n += len(net.boxes(b, box_thresh, max_dets=20000)[0])
+            n += len(net.boxes(b, box_thresh, max_dets=2048)[0])
         return n
 
     u8_step()

@@ -55,7 +55,10 @@ constexpr int tap_off(int k)
 }  // namespace
 
 template <int BM, int BN, int WM, int WN, int P, int ROWS>
-__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
+#ifndef DK_DIRECT_MIN_BLOCKS
+#define DK_DIRECT_MIN_BLOCKS 1
+#endif
+__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64, DK_DIRECT_MIN_BLOCKS)
 conv3x3_direct_f32(const ConvArgs p)
 {
   constexpr int NWN = BN / WN;
