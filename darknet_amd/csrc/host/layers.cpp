@@ -212,6 +212,13 @@ void ForwardConvolutionalLayerGpu(layer* l, NetworkState state)
     out = l->out_view;  // channel slice of the consuming route's buffer
     out_ctot = l->out_view_ctot;
   }
+  if (state.net->cudnn_half && !state.train && l->weights_half_gpu && !act_in)
+  {
+    if (dk_conv_forward_half_direct(&d, state.input, l->weights_half_gpu, l->biases_gpu, out, residual,
+            get_cuda_stream(), out_ctot))
+      error("ForwardConvolutionalLayerGpu (fp16 operands, direct) failed");
+    return;
+  }
   if (state.net->cudnn_half && !state.train && dk_conv_half_eligible(&d, l->index))
   {
     if (dk_conv_forward_half_strided(&d, state.input, l->weights_gpu, l->biases_gpu, out, residual,
@@ -625,6 +632,7 @@ void free_layer(layer* l, bool)
     cuda_free(l->variance_delta_gpu); cuda_free(l->mean_delta_gpu);
     cuda_free(l->x_gpu); cuda_free(l->x_norm_gpu);
     cuda_free(l->weights_gpu); cuda_free(l->weight_updates_gpu);
+    cuda_free((float*)l->weights_half_gpu);
     cuda_free(l->biases_gpu); cuda_free(l->bias_updates_gpu);
     cuda_free(l->scales_gpu); cuda_free(l->scale_updates_gpu);
     cuda_free(l->output_gpu); cuda_free(l->activation_input_gpu);

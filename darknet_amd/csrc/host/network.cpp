@@ -312,6 +312,25 @@ void DkPlanInference(Network* net)
         r->out_alias = DkLayerOut(src);
     }
   }
+  // 1c. fp16 path: pack the weights of the layers that take the direct fp16 kernel
+  for (int i = 0; i < net->n; ++i)
+  {
+    layer* l = &net->layers[i];
+    if (l->type != CONVOLUTIONAL)
+      continue;
+    cuda_free((float*)l->weights_half_gpu);
+    l->weights_half_gpu = nullptr;
+    const char* hd = getenv("DK_HALF_DIRECT");
+    if (!net->cudnn_half || l->batch_normalize || (hd && !atoi(hd)))
+      continue;
+    DkConvDesc hd2 = {l->batch, l->c, l->h, l->w, l->n, l->groups, l->size, l->stride_x, l->stride_y, l->dilation, l->pad, (int)l->activation};
+    const size_t halves = dk_conv_half_eligible(&hd2, i) ? dk_conv_half_direct_weights_size(&hd2) : 0;
+    if (!halves)
+      continue;
+    l->weights_half_gpu = cuda_make_array(nullptr, (halves + 1) / 2);
+    if (dk_conv_half_pack_weights(&hd2, l->weights_gpu, l->weights_half_gpu, get_cuda_stream()))
+      error("dk_conv_half_pack_weights failed");
+  }
   // 2. tap tables (must exist before any stream capture)
   for (int i = 0; i < net->n; ++i)
     if (net->layers[i].type == CONVOLUTIONAL)

@@ -28,3 +28,6 @@ bool dk_conv_config_applicable(const DkConvDesc* d, int cfg);
 int dk_transpose_weights_flip(const float* w, float* wt, int M, int C, int size, void* stream);
 // DK_FAST_MISH (default on): closed-form mish / mish gradient instead of the libm chains
 bool dk_fast_mish_enabled();
+// conv3x3_direct_f16.hip: fp16-operand patch-in-LDS kernel with weights pre-packed per layer
+int dk_conv_forward_half_direct(const DkConvDesc* d, const float* x, const void* packed_weights,
+    const float* biases, float* y, const float* residual, void* stream, int out_ctot);

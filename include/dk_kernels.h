@@ -98,6 +98,16 @@ DK_API int dk_shortcut_forward(const float* in, const float* from, float* out,
 DK_API int dk_upsample_forward(const float* in, int w, int h, int c, int batch,
     int stride, float scale, float* out, void* stream);
 
+/* fp16-operand path for 3x3/s1/p1 layers with c % 16 == 0 (the cuDNN half branch,
+ * src/convolutional_kernels.cu:357-456): number of halves of the re-laid-out weights
+ * [n][c/16][tap][16] (0: the layer does not take this kernel), and the one-time packing
+ * (fp32 -> fp16 round to nearest even).  The network plan packs once per layer at load. */
+DK_API size_t dk_conv_half_direct_weights_size(const DkConvDesc* d);
+DK_API int dk_conv_half_pack_weights(const DkConvDesc* d, const float* weights, void* packed, void* stream);
+/* y = act(conv(fp16(x), packed fp16 weights) + bias) (+ residual), fp32 accumulate */
+DK_API int dk_conv_forward_half_packed(const DkConvDesc* d, const float* x, const void* packed_weights,
+    const float* biases, float* y, const float* residual, void* stream);
+
 /* Device half of GetYoloDetections (src/yolo_layer.cpp:794-834): appends one record
  * {int tag, int image, int loc = n*w*h + i, x, y, w, h, objectness, classes...} (3 + 5 + classes
  * floats, ints stored bitwise) per predictor with objectness > thresh to records[], counting in

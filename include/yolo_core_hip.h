@@ -198,6 +198,7 @@ struct layer
   int conv_cfg;          /* tile configuration chosen by the autotuner, or -1 */
   /* zero-copy concatenation (inference plan): a producer whose only reader is a multi-input
    * [route] writes straight into that route's buffer; a single-input [route] is an alias */
+  void* weights_half_gpu; /* fp16 weights packed for conv3x3_direct_f16 (inference plan with cudnn_half), or NULL */
   int delta_in_arena;    /* delta_gpu points into net->delta_arena_gpu (not freed per layer) */
   float* out_view;       /* producer: where the output really goes (a channel slice), or NULL */
   int out_view_ctot;     /* producer: channels of the tensor out_view is a slice of */

@@ -41,6 +41,44 @@ def test_conv_half_vs_rounded_oracle(gpu, case):
     assert np.abs(full - ref).max() > 1e-5
 
 
+@pytest.mark.parametrize("case", [(2, 32, 19, 19, 64, "LEAKY"), (1, 512, 19, 19, 1024, "LEAKY"), (2, 64, 32, 32, 72, "MISH"),
+                                  (1, 128, 64, 64, 128, "MISH"), (1, 16, 128, 128, 40, "LINEAR"), (3, 48, 16, 16, 136, "LEAKY")])
+def test_conv_half_direct_vs_rounded_oracle(gpu, case):
+    """The patch-in-LDS fp16 kernel (weights packed [n][c/16][tap][16]) against the CPU fp32 path
+    on fp16-rounded inputs and weights, with and without a residual."""
+    batch, c, h, w, n, actname = case
+    act = getattr(O, actname)
+    rng = np.random.default_rng(abs(hash(case)) & 0xFFFF)
+    x = rng.uniform(-1, 1, (batch, c, h, w)).astype(np.float32)
+    wt = (rng.uniform(-1, 1, (n, c, 3, 3)) * np.sqrt(2.0 / (9 * c))).astype(np.float32)
+    bias = rng.uniform(-.5, .5, n).astype(np.float32)
+    res = rng.uniform(-1, 1, (batch, n, h, w)).astype(np.float32)
+    x16 = np.ascontiguousarray(x.astype(np.float16).astype(np.float32))
+    w16 = np.ascontiguousarray(wt.astype(np.float16).astype(np.float32))
+    ref, _ = orc_conv(x16, w16, bias, batch, c, h, w, n, 3, 1, 1, act)
+    L = gpu.lib()
+    VP = C.c_void_p
+    L.dk_conv_half_direct_weights_size.argtypes = [C.POINTER(gpu.DkConvDesc)]
+    L.dk_conv_half_direct_weights_size.restype = C.c_size_t
+    L.dk_conv_half_pack_weights.argtypes = [C.POINTER(gpu.DkConvDesc), VP, VP, VP]
+    L.dk_conv_forward_half_packed.argtypes = [C.POINTER(gpu.DkConvDesc)] + [VP] * 6
+    d = gpu.DkConvDesc(batch, c, h, w, n, 1, 3, 1, 1, 1, 1, act)
+    halves = L.dk_conv_half_direct_weights_size(C.byref(d))
+    assert halves == n * c * 9
+    dx, dw, db, dr = gpu.DeviceArray(x), gpu.DeviceArray(wt), gpu.DeviceArray(bias), gpu.DeviceArray(res)
+    dp = gpu.DeviceArray(n=(halves + 1) // 2)
+    dy = gpu.DeviceArray(n=ref.size)
+    assert L.dk_conv_half_pack_weights(C.byref(d), dw.ptr, dp.ptr, None) == 0
+    # packed layout: [n][c/16][tap][16] halves of the RNE-rounded weights
+    packed = np.frombuffer(dp.numpy().tobytes(), dtype=np.float16)[:halves].reshape(n, c // 16, 9, 16)
+    want = wt.astype(np.float16).reshape(n, c // 16, 16, 9).transpose(0, 1, 3, 2)
+    assert np.array_equal(packed, want)
+    assert L.dk_conv_forward_half_packed(C.byref(d), dx.ptr, dp.ptr, db.ptr, dy.ptr, dr.ptr, None) == 0
+    util.assert_close(dy.numpy().reshape(ref.shape), ref + res, "fp16 direct conv + residual %s" % (case,))
+    assert L.dk_conv_forward_half_packed(C.byref(d), dx.ptr, dp.ptr, db.ptr, dy.ptr, None, None) == 0
+    util.assert_close(dy.numpy().reshape(ref.shape), ref, "fp16 direct conv %s" % (case,))
+
+
 def test_csp_b1_half_vs_rounded_oracle(gpu, tmp_path):
     name = "yolov4-csp"
     wpath = str(tmp_path / "w.weights")
