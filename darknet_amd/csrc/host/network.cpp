@@ -197,13 +197,21 @@ static void autotune_convs(Network* net)
             continue;
           l->conv_cfg = c;
           l->forward_gpu(l, s);  // warm
-          CHECK_HIP(hipEventRecord(e0, st));
-          l->forward_gpu(l, s);
-          l->forward_gpu(l, s);
-          CHECK_HIP(hipEventRecord(e1, st));
-          CHECK_HIP(hipEventSynchronize(e1));
-          float ms = 0;
-          CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+          // minimum of three timings of two launches: a single noisy sample must not
+          // decide between shapes that are a few per cent apart
+          float ms = 1e30f;
+          for (int rep = 0; rep < 3; ++rep)
+          {
+            CHECK_HIP(hipEventRecord(e0, st));
+            l->forward_gpu(l, s);
+            l->forward_gpu(l, s);
+            CHECK_HIP(hipEventRecord(e1, st));
+            CHECK_HIP(hipEventSynchronize(e1));
+            float t = 0;
+            CHECK_HIP(hipEventElapsedTime(&t, e0, e1));
+            if (t < ms)
+              ms = t;
+          }
           if (ms < best_ms)
           {
             best_ms = ms;

@@ -104,7 +104,11 @@ inline long long conv_pick_partition(ConvArgs& a, size_t weight_bytes, int tile_
   a.tm_per = a.tiles_m;
   a.tn_per = a.tiles_n;
   const size_t l2_budget = (size_t)3 << 20;  // of the 4 MB per XCD, leave room for the input stream
+#ifdef DK_NO_PARTITION
+  if (false)
+#else
   if (a.groups == 1 && weight_bytes > l2_budget)
+#endif
   {
     int pm = 1;
     while (pm < 8 && pm * 2 <= a.tiles_m && weight_bytes / pm > l2_budget) pm *= 2;

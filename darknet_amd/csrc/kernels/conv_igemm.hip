@@ -51,7 +51,9 @@
 // AVEC: weights rows are read as float4 (needs K % 4 == 0).
 // BVEC: 1x1 / stride 1 / pad 0 / OHW % 4 == 0: the B tile is a plain strided
 //       matrix, read as float4 along n and written to LDS with ds_write_b128.
-template <int BM, int BN, int BK, int WM, int WN, bool AVEC, bool BVEC>
+// PF: prefetch distance in K tiles (1: the next tile's loads are in flight during the MFMAs;
+//     2: two tiles ahead -- small tiles whose K-tile time is far below a load's latency).
+template <int BM, int BN, int BK, int WM, int WN, bool AVEC, bool BVEC, int PF = 1>
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
     conv_igemm_f32(const ConvArgs p)
 {
@@ -199,10 +201,15 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
     }
   }
 
-  float ra[AVEC ? PAV * 4 : PA];
-  float rb[BVEC ? PBV * 4 : PB];
+  constexpr int NA = AVEC ? PAV * 4 : PA, NB = BVEC ? PBV * 4 : PB;
+  float ra2[PF][NA];
+  float rb2[PF][NB];
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, PF - 1>;
 
-  auto load_tile = [&](int k0) {
+  auto load_tile = [&](int k0, auto sc) {
+    float(&ra)[NA] = ra2[decltype(sc)::value];
+    float(&rb)[NB] = rb2[decltype(sc)::value];
     // ---- A (weights [M][K] row-major)
     if (AVEC)
     {
@@ -249,7 +256,9 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
     }
   };
 
-  auto store_tile = [&](float* st) {
+  auto store_tile = [&](float* st, auto sc) {
+    float(&ra)[NA] = ra2[decltype(sc)::value];
+    float(&rb)[NB] = rb2[decltype(sc)::value];
     float* As = st;
     float* Bs = st + A_FLOATS;
     if (AVEC)
@@ -300,20 +309,10 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
   const int nkt = (K + BK - 1) / BK;
   const int l31 = lane & 31, lh = lane >> 5;
 
-  load_tile(0);
-  store_tile(lds);
-  __syncthreads();
-
-  for (int kt = 0; kt < nkt; ++kt)
-  {
-    float* cur = lds + (kt & 1) * STAGE;
-    const bool more = (kt + 1) < nkt;
-    if (more)
-      load_tile((kt + 1) * BK);
-
-    // MFMA step s contracts k = 2s (lanes 0-31) and 2s+1 (lanes 32-63): every
-    // output accumulates its K products in ascending k, like the reference's
-    // gemm_nn (src/gemm.c:2223-2239).
+  // MFMA step s contracts k = 2s (lanes 0-31) and 2s+1 (lanes 32-63): every output
+  // accumulates its K products in ascending k, like the reference's gemm_nn
+  // (src/gemm.c:2223-2239).
+  auto compute = [&](const float* cur) {
     const float* As = cur + (wm * WM + l31) * AS + lh;
     const float* Bs = cur + A_FLOATS + lh * BN + wn * WN + l31;
 #pragma unroll
@@ -330,10 +329,49 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
+  };
 
-    if (more)
-      store_tile(lds + ((kt + 1) & 1) * STAGE);
+  if (PF == 1)
+  {
+    load_tile(0, I0{});
+    store_tile(lds, I0{});
     __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt)
+    {
+      const bool more = (kt + 1) < nkt;
+      if (more)
+        load_tile((kt + 1) * BK, I0{});
+      compute(lds + (kt & 1) * STAGE);
+      if (more)
+        store_tile(lds + ((kt + 1) & 1) * STAGE, I0{});
+      __syncthreads();
+    }
+  }
+  else
+  {
+    // two register sets: tile t lives in set t%2 until it is written to LDS buffer t%2
+    load_tile(0, I0{});
+    if (nkt > 1)
+      load_tile(BK, I1{});
+    store_tile(lds, I0{});
+    __syncthreads();
+    for (int kt = 0; kt < nkt; kt += 2)
+    {
+      if (kt + 2 < nkt)
+        load_tile((kt + 2) * BK, I0{});
+      compute(lds);
+      if (kt + 1 < nkt)
+        store_tile(lds + STAGE, I1{});
+      __syncthreads();
+      if (kt + 1 >= nkt)
+        break;
+      if (kt + 3 < nkt)
+        load_tile((kt + 3) * BK, I1{});
+      compute(lds + STAGE);
+      if (kt + 2 < nkt)
+        store_tile(lds, I0{});
+      __syncthreads();
+    }
   }
 
   conv_epilogue<BM, BN, WM, WN, TM, TN>(p, acc, m0, n0, g, wm, wn, l31, lh);
@@ -359,6 +397,7 @@ struct TileCfg
   const char* name;
   void (*kernel[4])(const ConvArgs);  // [AVEC + 2*BVEC]
   int threads;
+  int pf;
 };
 
 #define DK_CFG(BM, BN, BK, WM, WN, EFF)                                                     \
@@ -368,7 +407,17 @@ struct TileCfg
             conv_igemm_f32<BM, BN, BK, WM, WN, true, false>,                                \
             conv_igemm_f32<BM, BN, BK, WM, WN, false, true>,                                \
             conv_igemm_f32<BM, BN, BK, WM, WN, true, true>},                                \
-        (BM / WM) * (BN / WN) * 64                                                          \
+        (BM / WM) * (BN / WN) * 64, 1                                                       \
+  }
+// prefetch distance 2 (two register sets)
+#define DK_CFG_PF2(BM, BN, BK, WM, WN, EFF)                                                 \
+  {                                                                                         \
+    BM, BN, BK, WM, WN, EFF, #BM "x" #BN "x" #BK "_w" #WM "x" #WN "_pf2",                   \
+        {conv_igemm_f32<BM, BN, BK, WM, WN, false, false, 2>,                               \
+            conv_igemm_f32<BM, BN, BK, WM, WN, true, false, 2>,                             \
+            conv_igemm_f32<BM, BN, BK, WM, WN, false, true, 2>,                             \
+            conv_igemm_f32<BM, BN, BK, WM, WN, true, true, 2>},                             \
+        (BM / WM) * (BN / WN) * 64, 2                                                       \
   }
 
 const TileCfg g_cfgs[] = {
@@ -381,6 +430,9 @@ const TileCfg g_cfgs[] = {
     DK_CFG(64, 256, 16, 32, 128, 0.95f),
     DK_CFG(128, 64, 32, 64, 32, 0.97f),
     DK_CFG(64, 64, 32, 32, 32, 0.92f),
+    DK_CFG_PF2(64, 64, 16, 32, 32, 0.90f),
+    DK_CFG_PF2(64, 64, 32, 32, 32, 0.90f),
+    DK_CFG_PF2(128, 64, 16, 64, 32, 0.90f),
 };
 const int g_ncfg = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
 
@@ -610,8 +662,8 @@ extern "C" __attribute__((visibility("default"))) const char* dk_conv_kernel_nam
   if (idx < 0)
     return nullptr;
   const TileCfg& c = g_cfgs[idx / 4];
-  snprintf(buf, sizeof(buf), "conv_igemm_f32<%d, %d, %d, %d, %d, %s, %s>", c.bm, c.bn, c.bk, c.wm,
-      c.wn, (idx & 1) ? "true" : "false", (idx & 2) ? "true" : "false");
+  snprintf(buf, sizeof(buf), "conv_igemm_f32<%d, %d, %d, %d, %d, %s, %s, %d>", c.bm, c.bn, c.bk, c.wm,
+      c.wn, (idx & 1) ? "true" : "false", (idx & 2) ? "true" : "false", c.pf);
   return buf;
 }
 

@@ -30,7 +30,7 @@ for (b, c, h, w, n, size, stride, pad) in SHAPES:
             for _ in range(iters):
                 L.dk_conv_forward(C.byref(d), dx.ptr, dw.ptr, db.ptr, dy.ptr, None, None, None)
             out = (C.c_double * 192)()
-            L.dk_profile_read(out, 64)
+            L.dk_profile_read(out, 128)
             L.dk_profile_enable(0)
             res.append(sum(out[(cfg * 4 + v) * 3 + 1] for v in range(4)) / sum(out[(cfg * 4 + v) * 3 + 2] for v in range(4)))
         print("c%-4d %3dx%-3d n%-4d k%d s%d act%-4x | " % (c, h, w, n, size, stride, act) + " ".join("%6.1f" % r for r in res), flush=True)

@@ -63,8 +63,8 @@ def main():
             L.dk_profile_enable(1)
             for _ in range(iters):
                 L.dk_conv_forward(C.byref(d), dx.ptr, wt.ptr, bs.ptr, dy.ptr, None, None, None)
-            out = (C.c_double * (3 * 64))()
-            L.dk_profile_read(out, 64)
+            out = (C.c_double * (3 * 128))()
+            L.dk_profile_read(out, 128)
             L.dk_profile_enable(0)
             ms = sum(out[(cfgi * 4 + v) * 3 + 2] for v in range(4)) / iters
             g1 = sum(out[(cfgi * 4 + v) * 3 + 1] for v in range(4)) / iters
