@@ -13,5 +13,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats -- python3
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/$OUT/$c -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/$OUT/$c.log 2>&1
 done
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $R/$OUT/MFMA -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/$OUT/MFMA.log 2>&1
 python3 $R/tools/pmc_summarize.py $R/$OUT
 cp $R/$OUT/stats/*/*kernel_stats.csv $R/$OUT/kernel_stats.csv
+python3 $R/tools/kernel_table.py $R/$OUT > $R/$OUT/kernel_table.md
