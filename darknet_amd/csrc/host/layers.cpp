@@ -194,9 +194,25 @@ void ForwardConvolutionalLayerGpu(layer* l, NetworkState state)
     ForwardConvTrainGpu(l, state);
     return;
   }
+  if (l->dual_slave && !state.train)
+    return;  // written by the dual launch of layer l->index - 2
   DkConvDesc d = conv_desc(l);
   float* out = l->output_gpu;
   const float* residual = nullptr;
+  if (l->dual_with > 0 && !state.train)
+  {
+    layer* l2 = &state.net->layers[l->dual_with];
+    DkConvDual dual;
+    dual.y2 = l2->out_view ? l2->out_view : l2->output_gpu;
+    dual.m_split = l->n;
+    dual.out_ctot2 = l2->out_view ? l2->out_view_ctot : 0;
+    d.n = l->n + l2->n;
+    if (dk_conv_forward_cfg(&d, state.input, l->dual_weights_gpu, l->dual_biases_gpu,
+            l->out_view ? l->out_view : l->output_gpu, nullptr, nullptr, get_cuda_stream(), l->conv_cfg,
+            l->out_view ? l->out_view_ctot : 0, &dual))
+      error("ForwardConvolutionalLayerGpu (dual output) failed");
+    return;
+  }
   if (l->fuse_residual_from >= 0)
   {
     // shortcut folded into this conv's epilogue: write the sum straight into the
@@ -633,6 +649,7 @@ void free_layer(layer* l, bool)
     cuda_free(l->x_gpu); cuda_free(l->x_norm_gpu);
     cuda_free(l->weights_gpu); cuda_free(l->weight_updates_gpu);
     cuda_free((float*)l->weights_half_gpu);
+    cuda_free(l->dual_weights_gpu); cuda_free(l->dual_biases_gpu);
     cuda_free(l->biases_gpu); cuda_free(l->bias_updates_gpu);
     cuda_free(l->scales_gpu); cuda_free(l->scale_updates_gpu);
     cuda_free(l->output_gpu); cuda_free(l->activation_input_gpu);

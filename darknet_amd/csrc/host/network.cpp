@@ -177,10 +177,11 @@ static void autotune_convs(Network* net)
     layer* l = &net->layers[i];
     DkConvDesc hd = {l->batch, l->c, l->h, l->w, l->n, l->groups, l->size, l->stride_x, l->stride_y, l->dilation, l->pad, (int)l->activation};
     const bool half_layer = net->cudnn_half && l->type == CONVOLUTIONAL && dk_conv_half_eligible(&hd, i);
-    if (l->type == CONVOLUTIONAL && !l->batch_normalize && !half_layer)
+    if (l->type == CONVOLUTIONAL && !l->batch_normalize && !half_layer && !l->dual_slave)
     {
       std::vector<int> key = {l->batch, l->c, l->h, l->w, l->n, l->groups, l->size, l->stride_x,
-          l->stride_y, l->dilation, l->pad, (int)l->activation, l->fuse_residual_from >= 0};
+          l->stride_y, l->dilation, l->pad, (int)l->activation, l->fuse_residual_from >= 0,
+          l->dual_with > 0 ? net->layers[l->dual_with].n : 0};
       auto it = cache.find(key);
       if (it != cache.end())
         l->conv_cfg = it->second;
@@ -318,6 +319,52 @@ void DkPlanInference(Network* net)
       layer* src = &net->layers[r->input_layers[0]];
       if (!src->out_view && src->outputs == r->outputs)
         r->out_alias = DkLayerOut(src);
+    }
+  }
+  // 1b'. the two 1x1 branches of a CSP stage read the same tensor (conv, [route -2], conv):
+  // one launch with concatenated filters computes both and reads the tensor once
+  for (int i = 0; i < net->n; ++i)
+  {
+    layer* l = &net->layers[i];
+    l->dual_with = 0;
+    l->dual_slave = 0;
+    if (l->type == CONVOLUTIONAL)
+    {
+      cuda_free(l->dual_weights_gpu); l->dual_weights_gpu = nullptr;
+      cuda_free(l->dual_biases_gpu); l->dual_biases_gpu = nullptr;
+    }
+  }
+  {
+    const char* ed = getenv("DK_DUAL");
+    const bool enable = g_dk_fusion && !(ed && !atoi(ed));
+    for (int i = 1; enable && i + 2 < net->n; ++i)
+    {
+      layer* a = &net->layers[i];
+      layer* r = &net->layers[i + 1];
+      layer* b = &net->layers[i + 2];
+      auto plain1x1 = [](const layer* c) {
+        return c->type == CONVOLUTIONAL && !c->batch_normalize && c->size == 1 && c->stride_x == 1 &&
+               c->stride_y == 1 && c->groups == 1 && c->pad == 0 && c->fuse_residual_from < 0 && !c->dual_slave &&
+               c->dual_with == 0;
+      };
+      if (!plain1x1(a) || !plain1x1(b) || r->type != ROUTE || !r->out_alias)
+        continue;
+      if (r->out_alias != DkLayerOut(&net->layers[i - 1]))
+        continue;  // b must read the tensor a reads
+      if (a->c != b->c || a->h != b->h || a->w != b->w || a->activation != b->activation || a->n % 64 ||
+          a->batch != b->batch)
+        continue;
+      const size_t k = (size_t)a->c;
+      a->dual_weights_gpu = cuda_make_array(nullptr, (size_t)(a->n + b->n) * k);
+      a->dual_biases_gpu = cuda_make_array(nullptr, (size_t)(a->n + b->n));
+      hipStream_t st = get_cuda_stream();
+      CHECK_HIP(hipMemcpyAsync(a->dual_weights_gpu, a->weights_gpu, (size_t)a->n * k * sizeof(float), hipMemcpyDeviceToDevice, st));
+      CHECK_HIP(hipMemcpyAsync(a->dual_weights_gpu + (size_t)a->n * k, b->weights_gpu, (size_t)b->n * k * sizeof(float), hipMemcpyDeviceToDevice, st));
+      CHECK_HIP(hipMemcpyAsync(a->dual_biases_gpu, a->biases_gpu, (size_t)a->n * sizeof(float), hipMemcpyDeviceToDevice, st));
+      CHECK_HIP(hipMemcpyAsync(a->dual_biases_gpu + a->n, b->biases_gpu, (size_t)b->n * sizeof(float), hipMemcpyDeviceToDevice, st));
+      CHECK_HIP(hipStreamSynchronize(st));
+      a->dual_with = i + 2;
+      b->dual_slave = 1;
     }
   }
   // 1c. fp16 path: pack the weights of the layers that take the direct fp16 kernel

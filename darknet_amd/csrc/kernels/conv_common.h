@@ -40,6 +40,11 @@ struct ConvArgs
   // pm = 1 is the N-major default (xcd_remap)
   int pm, tm_per, tn_per;
   double inv_tm_per;
+  // dual output (two convolutions of the same input in one launch): filters >= m_split go to y2
+  // (a tensor with Mtot2 channels); m_split is a multiple of the tile's BM, 0 = single output
+  float* y2;
+  unsigned y2_bytes;
+  int Mtot2, m_split;
 };
 
 // exact floor(n / d) for 0 <= n < 2^31, d > 0, given inv = 1.0 / d: the double estimate is within
@@ -162,7 +167,13 @@ template <int BM, int BN, int WM, int WN, int TM, int TN>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[TM][TN], int m0,
     int n0, int g, int wm, int wn, int l31, int lh)
 {
-  __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.y_bytes, 0x00020000);
+  // dual-output launches: the M tiles at or above m_split write the second tensor
+  const bool second = p.m_split > 0 && m0 >= p.m_split;
+  float* const ybuf = second ? p.y2 : p.y;
+  const unsigned ybytes = second ? p.y2_bytes : p.y_bytes;
+  const int mtot = second ? p.Mtot2 : p.Mtot;
+  const int msub = second ? p.m_split : 0;
+  __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)ybuf, 0, ybytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, p.residual ? p.y_bytes : 0u, 0x00020000);
   __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc((void*)p.act_in, 0, p.act_in ? p.y_bytes : 0u, 0x00020000);
   const bool has_res = p.residual != nullptr, has_ain = p.act_in != nullptr;
@@ -177,7 +188,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
     const int nn = nv ? n : 0;
     const int b = fdiv(nn, p.OHW, p.inv_OHW);
     const int pix = nn - b * p.OHW;
-    obase[j] = nv ? (unsigned)((b * p.Mtot + g * p.M) * p.OHW + pix) * 4u : 0xFFFFFFFFu;
+    obase[j] = nv ? (unsigned)((b * mtot + g * p.M) * p.OHW + pix) * 4u : 0xFFFFFFFFu;
   }
   const unsigned row_bytes = (unsigned)p.OHW * 4u;
   // generic per-element path: edge tiles, exact mish / logistic / relu, pre-activation store
@@ -193,7 +204,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
         if (CHECK && m >= p.M)
           continue;
         const float bv = p.bias ? p.bias[g * p.M + m] : 0.f;
-        const unsigned mo = (unsigned)m * row_bytes;
+        const unsigned mo = (unsigned)(m - msub) * row_bytes;
 #pragma unroll
         for (int j = 0; j < TN; ++j)
         {
@@ -225,7 +236,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
         (void*)(p.bias ? p.bias + g * p.M : p.w), 0, p.bias ? (unsigned)p.M * 4u : 0u, 0x00020000);
     unsigned vo[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) vo[j] = obase[j] + (unsigned)mlane * row_bytes;
+    for (int j = 0; j < TN; ++j) vo[j] = obase[j] + (unsigned)(mlane - msub) * row_bytes;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
     {

@@ -705,7 +705,7 @@ extern "C" int dk_conv_forward(const DkConvDesc* d, const float* x, const float*
 
 int dk_conv_forward_cfg(const DkConvDesc* d, const float* x, const float* weights,
     const float* biases, float* y, const float* residual, float* activation_input, void* stream,
-    int cfg_override, int out_ctot)
+    int cfg_override, int out_ctot, const DkConvDual* dual)
 {
   if (!d || !x || !weights || !y || d->groups < 1 || d->c % d->groups || d->n % d->groups ||
       d->size < 1 || d->stride_x < 1 || d->stride_y < 1 || d->dilation < 1)
@@ -744,18 +744,35 @@ int dk_conv_forward_cfg(const DkConvDesc* d, const float* x, const float* weight
     fprintf(stderr, "dk_conv_forward: a channel-slice output takes no residual / pre-activation\n");
     return 1;
   }
-  const int Mtot = out_ctot ? out_ctot : d->n;
+  if (dual && (d->groups != 1 || residual || activation_input || dual->m_split <= 0 ||
+                  dual->m_split >= d->n || dual->m_split % 32 || !dual->y2))
+  {
+    fprintf(stderr, "dk_conv_forward: invalid dual-output request\n");
+    return 1;
+  }
+  const int n1 = dual ? dual->m_split : d->n;           // filters of the first output
+  const int n2 = dual ? d->n - dual->m_split : 0;
+  const int Mtot = out_ctot ? out_ctot : n1;
+  const int Mtot2 = dual ? (dual->out_ctot2 ? dual->out_ctot2 : n2) : 0;
   const size_t out_img = (size_t)Mtot * OH * OW;  // batch stride of the output
+  const size_t out_img2 = (size_t)Mtot2 * OH * OW;
   // the gather uses 32-bit byte offsets checked by the buffer descriptor:
   // process the batch in chunks whose input stays below 2 GiB
   const size_t max_elems = (size_t)1 << 29;  // byte offsets stay below 2^31: bit 31 is the "masked" flag
   int chunk = d->batch;
-  if (in_img * (size_t)chunk >= max_elems || out_img * (size_t)chunk >= ((size_t)1 << 30))
+  if (in_img * (size_t)chunk >= max_elems || out_img * (size_t)chunk >= ((size_t)1 << 30) ||
+      out_img2 * (size_t)chunk >= ((size_t)1 << 30))
   {
     chunk = (int)((max_elems - 1) / in_img);
     const int c2 = (int)((((size_t)1 << 30) - 1) / out_img);
     if (c2 < chunk)
       chunk = c2;
+    if (out_img2)
+    {
+      const int c3 = (int)((((size_t)1 << 30) - 1) / out_img2);
+      if (c3 < chunk)
+        chunk = c3;
+    }
     if (chunk < 1)
     {
       fprintf(stderr, "dk_conv_forward: one image exceeds the 4 GiB addressing window\n");
@@ -778,7 +795,11 @@ int dk_conv_forward_cfg(const DkConvDesc* d, const float* x, const float* weight
     a.ktab = pl.ktab;
     a.x_bytes = (unsigned)(in_img * nb * sizeof(float));
     a.w_bytes = (unsigned)((size_t)M * K * sizeof(float));
-    a.y_bytes = (unsigned)((out_img * (nb - 1) + (size_t)d->n * OH * OW) * sizeof(float));
+    a.y_bytes = (unsigned)((out_img * (nb - 1) + (size_t)n1 * OH * OW) * sizeof(float));
+    a.y2 = dual ? dual->y2 + (size_t)b0 * out_img2 : nullptr;
+    a.y2_bytes = dual ? (unsigned)((out_img2 * (nb - 1) + (size_t)n2 * OH * OW) * sizeof(float)) : 0u;
+    a.Mtot2 = Mtot2;
+    a.m_split = dual ? dual->m_split : 0;
     a.C = C; a.H = d->h; a.W = d->w; a.Ctot = d->c;
     a.M = M; a.Mtot = Mtot; a.K = K;
     a.OH = OH; a.OW = OW; a.OHW = OH * OW;
@@ -814,7 +835,9 @@ int dk_conv_forward_cfg(const DkConvDesc* d, const float* x, const float* weight
       }
       continue;
     }
-    const int ci = (cfg_override >= 0 && cfg_override < g_ncfg) ? cfg_override : pick_cfg(M, a.N, d->groups);
+    int ci = (cfg_override >= 0 && cfg_override < g_ncfg) ? cfg_override : pick_cfg(M, a.N, d->groups);
+    if (dual && dual->m_split % g_cfgs[ci].bm)
+      ci = 3;  // 64x64: every dual split is a multiple of 64 rows (checked by the planner)
     const TileCfg& c = g_cfgs[ci];
     a.tiles_m = (M + c.bm - 1) / c.bm;
     a.tiles_n = (a.N + c.bn - 1) / c.bn;

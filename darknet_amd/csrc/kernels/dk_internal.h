@@ -7,9 +7,17 @@
 // dk_conv_forward with an explicit tile configuration (cfg < 0: heuristic).
 // out_ctot > 0: `y` is a channel slice of a wider tensor with out_ctot channels
 // (zero-copy concatenation: batch stride = out_ctot*oh*ow); no residual then.
+// dual != nullptr: ONE launch computes two convolutions of the same input (d->n = n1 + n2 filters,
+// weights/biases concatenated): filters [0, m_split) go to y, filters [m_split, d->n) to dual->y2
+// (each optionally a channel slice, out_ctot / out_ctot2).
+struct DkConvDual
+{
+  float* y2;
+  int m_split, out_ctot2;
+};
 int dk_conv_forward_cfg(const DkConvDesc* d, const float* x, const float* weights,
     const float* biases, float* y, const float* residual, float* activation_input, void* stream,
-    int cfg, int out_ctot = 0);
+    int cfg, int out_ctot = 0, const DkConvDual* dual = nullptr);
 int dk_conv_forward_half_strided(const DkConvDesc* d, const float* x, const float* weights,
     const float* biases, float* y, const float* residual, float* activation_input, void* stream,
     int out_ctot);

@@ -198,6 +198,11 @@ struct layer
   int conv_cfg;          /* tile configuration chosen by the autotuner, or -1 */
   /* zero-copy concatenation (inference plan): a producer whose only reader is a multi-input
    * [route] writes straight into that route's buffer; a single-input [route] is an alias */
+  /* two 1x1 convolutions of the same tensor (the two branches of a CSP stage) in one launch:
+   * the first conv carries the concatenated weights/biases and writes both outputs */
+  int dual_with;         /* index of the second conv, or 0 */
+  int dual_slave;        /* 1: computed by an earlier layer's dual launch */
+  float *dual_weights_gpu, *dual_biases_gpu;
   void* weights_half_gpu; /* fp16 weights packed for conv3x3_direct_f16 (inference plan with cudnn_half), or NULL */
   int delta_in_arena;    /* delta_gpu points into net->delta_arena_gpu (not freed per layer) */
   float* out_view;       /* producer: where the output really goes (a channel slice), or NULL */
