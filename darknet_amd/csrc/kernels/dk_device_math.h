@@ -63,6 +63,21 @@ __device__ __forceinline__ float dk_activate(float x, int a)
     case DK_MISH: return dk_mish(x);
     case DK_LOGISTIC: return dk_logistic(x);
     case DK_RELU: return x * (x > 0.f);
+    // the rarer kinds of activate() (src/activations.c:97-137, scalar definitions
+    // src/activations.h:60-138; that file is C: unsuffixed literals are double)
+    case 2: /* RELU6 */ return fminf(fmaxf(x, 0.f), 6.f);
+    case 3: /* RELIE */ return (x > 0.f) ? x : .01f * x;
+    case 5: /* RAMP */ return x * (x > 0.f) + .1f * x;
+    case 6: /* TANH */ return dk_tanh(x);
+    case 7: /* PLSE */ return (x < -4.f) ? .01f * (x + 4.f) : (x > 4.f) ? .01f * (x - 4.f) + 1.f : .125f * x + .5f;
+    case 9: /* ELU */ return (x >= 0.f) * x + (x < 0.f) * (expf(x) - 1.f);
+    case 10: /* LOGGY */ return 2.f / (1.f + expf(-x)) - 1.f;
+    case 12: /* HARDTAN */ return (x < -1.f) ? -1.f : (x > 1.f) ? 1.f : x;
+    case 13: /* LHTAN */ return (x < 0.f) ? .001f * x : (x > 1.f) ? .001f * (x - 1.f) + 1.f : x;
+    case 14: /* SELU */ return (x >= 0.f) * 1.0507f * x + (x < 0.f) * 1.0507f * 1.6732f * (expf(x) - 1.f);
+    case 15: /* GELU */
+      return (float)(0.5 * (double)x * (1 + (double)tanhf((float)(0.797885 * (double)x + 0.035677 * (double)powf(x, 3.f)))));
+    case 16: /* SWISH */ return x * dk_logistic(x);
     default: return x;
   }
 }

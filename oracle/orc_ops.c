@@ -299,7 +299,30 @@ void orc_activate_array(float* x, int n, int a)
     for (int i = 0; i < n; ++i) x[i] = x[i] * (x[i] > 0);
     return;
   }
-  abort(); /* unsupported activation in the oracle */
+  /* the remaining kinds go through activate() (src/activations.c:97-137) with the scalar
+   * definitions of src/activations.h:60-138 -- compiled as C: unsuffixed literals are double */
+  for (int i = 0; i < n; ++i)
+  {
+    const float v = x[i];
+    float r;
+    switch (a)
+    {
+      case 2: /* RELU6 */ r = ((((v > 0) ? v : 0) < 6) ? ((v > 0) ? v : 0) : 6); break;
+      case 3: /* RELIE */ r = (v > 0) ? v : .01f * v; break;
+      case 5: /* RAMP */ r = v * (v > 0) + .1f * v; break;
+      case 6: /* TANH */ r = (2 / (1 + expf(-2 * v)) - 1); break;
+      case 7: /* PLSE */ r = (v < -4) ? .01f * (v + 4) : (v > 4) ? .01f * (v - 4) + 1 : .125f * v + .5f; break;
+      case 9: /* ELU */ r = (v >= 0) * v + (v < 0) * (expf(v) - 1); break;
+      case 10: /* LOGGY */ r = 2.f / (1.f + expf(-v)) - 1; break;
+      case 12: /* HARDTAN */ r = (v < -1) ? -1 : (v > 1) ? 1 : v; break;
+      case 13: /* LHTAN */ r = (v < 0) ? .001f * v : (v > 1) ? .001f * (v - 1) + 1 : v; break;
+      case 14: /* SELU */ r = (v >= 0) * 1.0507f * v + (v < 0) * 1.0507f * 1.6732f * (expf(v) - 1); break;
+      case 15: /* GELU */ r = (0.5 * v * (1 + tanhf(0.797885 * v + 0.035677 * powf(v, 3)))); break;
+      case 16: /* SWISH: activate_array_swish, src/activations.c:170-182 */ r = v * logistic_f(v); break;
+      default: abort(); /* unsupported activation in the oracle */
+    }
+    x[i] = r;
+  }
 }
 
 /* activate_array (src/activations.c:142-170): LEAKY here is the float

@@ -2,6 +2,7 @@
 seeded inputs.  fp32 activations within util.REL (1e-4, definition in util.py);
 integer outputs (maxpool argmax indexes) bit-exact."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -43,13 +44,15 @@ CONV_CASES = [
     (2, 16, 14, 14, 32, 5, 1, 2, "LINEAR", 1, 1),     # 5x5
     (1, 512, 19, 19, 1024, 3, 1, 1, "LEAKY", 1, 1),   # yolov4 neck shape, K=4608
     (5, 4, 9, 7, 10, 3, 1, 1, "LINEAR", 1, 1),        # N spans image boundaries inside one tile
+    (2, 16, 13, 13, 24, 3, 1, 1, "SWISH", 1, 1),      # sibling-cfg activations through the fused epilogue
+    (2, 8, 10, 10, 16, 1, 1, 0, "RELU6", 1, 1),
 ]
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_forward_vs_oracle(gpu, case):
     batch, c, h, w, n, size, stride, pad, actname, groups, dil = case
-    act = getattr(O, actname) if hasattr(O, actname) else {"RELU": 1}[actname]
+    act = getattr(O, actname) if hasattr(O, actname) else {"RELU": 1, "RELU6": 2, "SWISH": 16}[actname]
     rng = np.random.default_rng(hash(case) & 0xFFFF)
     x = rng.uniform(-1, 1, (batch, c, h, w)).astype(np.float32)
     fan = size * size * c // groups
@@ -228,6 +231,18 @@ def test_activations_grid(gpu):
             assert np.array_equal(got, ref)
         else:
             util.assert_close(got, ref, "logistic", rel=1e-6, atol_rms=1e-7)
+    # the rarer activation kinds: exact for the piecewise-linear ones, libm-vs-device ulps for the rest
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "ops.npz"))
+    grid = np.ascontiguousarray(gold["act_grid"])
+    for name, act in (("relu6", 2), ("relie", 3), ("ramp", 5), ("tanh", 6), ("plse", 7), ("elu", 9), ("loggy", 10),
+                      ("hardtan", 12), ("lhtan", 13), ("selu", 14), ("gelu", 15), ("swish", 16)):
+        d = gpu.DeviceArray(grid)
+        assert G.dk_activate_array(d.ptr, grid.size, act, None) == 0
+        got, ref = d.numpy(), gold["act_" + name]      # reference's own values
+        if name in ("relu6", "relie", "ramp", "plse", "hardtan", "lhtan"):
+            assert np.array_equal(got, ref), name
+        else:
+            assert np.all(np.abs(got - ref) <= 1e-5 * np.abs(ref) + 3e-7), (name, np.abs(got - ref).max())
     ref = np.zeros_like(x)
     ain = np.zeros_like(x)
     L.orc_activate_array_mish(O.fptr(x), x.size, O.fptr(ain), O.fptr(ref))

@@ -45,10 +45,19 @@ def test_gemm(ops):
         assert np.array_equal(Cm, ops[f"gemm_{i}_C"]), i
 
 
+EXTRA_ACTIVATIONS = (('relu6', 2), ('relie', 3), ('ramp', 5), ('tanh', 6), ('plse', 7), ('elu', 9), ('loggy', 10),
+                     ('hardtan', 12), ('lhtan', 13), ('selu', 14), ('gelu', 15), ('swish', 16))
+
+
 def test_activations(ops):
     L = O.lib()
     g = ops["act_grid"]
     for name, a in (("leaky", O.LEAKY), ("logistic", O.LOGISTIC), ("relu", O.RELU)):
+        x = g.copy()
+        L.orc_activate_array(O.fptr(x), x.size, a)
+        assert np.array_equal(x, ops["act_" + name]), name
+    # the rarer kinds of activate() and swish (ACTIVATION enum values, src/yolo_core.h:69-92)
+    for name, a in EXTRA_ACTIVATIONS:
         x = g.copy()
         L.orc_activate_array(O.fptr(x), x.size, a)
         assert np.array_equal(x, ops["act_" + name]), name

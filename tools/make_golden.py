@@ -86,6 +86,18 @@ def gen_ops():
         x = grid.copy()
         L.activate_array_cpu_custom(fp(x), x.size, a)
         out["act_" + name] = x
+    # the rarer kinds of activate() and swish (sibling cfgs: efficientnet, mobilenet, ...)
+    for name, a in (("relu6", 2), ("relie", 3), ("ramp", 5), ("tanh", 6), ("plse", 7), ("elu", 9), ("loggy", 10),
+                    ("hardtan", 12), ("lhtan", 13), ("selu", 14), ("gelu", 15)):
+        x = grid.copy()
+        L.activate_array_cpu_custom(fp(x), x.size, a)
+        out["act_" + name] = x
+    x = grid.copy()
+    sig = np.zeros_like(x)
+    y = np.zeros_like(x)
+    L.activate_array_swish.argtypes = [FP, C.c_int, FP, FP]
+    L.activate_array_swish(fp(x), x.size, fp(sig), fp(y))
+    out["act_swish"] = y
     x = grid.copy()
     ain = np.zeros_like(x)
     y = np.zeros_like(x)
@@ -357,5 +369,7 @@ if __name__ == "__main__":
         gen_train()
     elif len(sys.argv) > 1 and sys.argv[1] == "yololoss":
         gen_yololoss()
+    elif len(sys.argv) > 1 and sys.argv[1] == "ops":
+        gen_ops()
     else:
         main()
