@@ -192,6 +192,7 @@ static void autotune_convs(Network* net)
         s.index = i;
         int best = -1;
         float best_ms = 1e30f;
+        std::vector<float> times(ncfg, 0.f);
         for (int c = 0; c < ncfg; ++c)
         {
           if (!dk_conv_config_applicable(&hd, c))
@@ -213,12 +214,20 @@ static void autotune_convs(Network* net)
             if (t < ms)
               ms = t;
           }
+          times[c] = ms;
           if (ms < best_ms)
           {
             best_ms = ms;
             best = c;
           }
         }
+        // hysteresis in favour of the heuristic's shape: shapes within 3 % of each other are
+        // separated by timing noise, not by merit (observed: whole groups of layers flipping
+        // between runs), and the heuristic is right on average
+        const int heur = dk_conv_pick_config(&hd);
+        static const float hyst = getenv("DK_TUNE_HYST") ? (float)atof(getenv("DK_TUNE_HYST")) : 3.0f;  // per cent
+        if (heur >= 0 && heur < ncfg && times[heur] > 0 && best != heur && times[heur] <= best_ms * (1.f + hyst / 100.f))
+          best = heur;
         l->conv_cfg = best;
         cache[key] = best;
       }
