@@ -74,6 +74,20 @@ def main():
     ap.add_argument("--half", action="store_true", help="fp16 operands / fp32 accumulate on the layers the reference's rule admits (config C5)")
     args = ap.parse_args()
 
+    # N > 1 without a launcher: start the N ranks ourselves as fresh child processes (one per GPU,
+    # rendezvous on 127.0.0.1) BEFORE anything here touches the GPU, relay rank 0's JSON line and
+    # exit with the children's code.  Under torch.distributed.run (WORLD_SIZE set) this is skipped.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
+
     import numpy as np
     import torch  # device sync + torch.distributed (RCCL) only
     import darknet_amd as dk

@@ -271,7 +271,28 @@ void PushConvolutionalLayer(layer* l)
     cuda_push_array(l->rolling_mean_gpu, l->rolling_mean, l->n);
     cuda_push_array(l->rolling_variance_gpu, l->rolling_variance, l->n);
   }
-  CHECK_HIP(hipStreamSynchronize(get_cuda_stream()));
+  // copies the inference plan derived from the weights follow them (same allocations, so a
+  // captured graph stays valid): the concatenated filters of a dual launch, the packed fp16 set
+  hipStream_t st = get_cuda_stream();
+  if (l->dual_peer)
+  {
+    layer* a = l->dual_slave ? l->dual_peer : l;
+    layer* b = a->dual_peer;
+    if (a->dual_weights_gpu && b)
+    {
+      CHECK_HIP(hipMemcpyAsync(a->dual_weights_gpu, a->weights_gpu, (size_t)a->nweights * sizeof(float), hipMemcpyDeviceToDevice, st));
+      CHECK_HIP(hipMemcpyAsync(a->dual_weights_gpu + a->nweights, b->weights_gpu, (size_t)b->nweights * sizeof(float), hipMemcpyDeviceToDevice, st));
+      CHECK_HIP(hipMemcpyAsync(a->dual_biases_gpu, a->biases_gpu, (size_t)a->n * sizeof(float), hipMemcpyDeviceToDevice, st));
+      CHECK_HIP(hipMemcpyAsync(a->dual_biases_gpu + a->n, b->biases_gpu, (size_t)b->n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+  }
+  if (l->weights_half_gpu)
+  {
+    DkConvDesc d = conv_desc(l);
+    if (dk_conv_half_pack_weights(&d, l->weights_gpu, l->weights_half_gpu, st))
+      error("PushConvolutionalLayer: re-packing the fp16 weights failed");
+  }
+  CHECK_HIP(hipStreamSynchronize(st));
 }
 
 void PullConvolutionalLayer(layer* l)

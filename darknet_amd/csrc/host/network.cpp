@@ -337,6 +337,7 @@ void DkPlanInference(Network* net)
     layer* l = &net->layers[i];
     l->dual_with = 0;
     l->dual_slave = 0;
+    l->dual_peer = nullptr;
     if (l->type == CONVOLUTIONAL)
     {
       cuda_free(l->dual_weights_gpu); l->dual_weights_gpu = nullptr;
@@ -374,6 +375,8 @@ void DkPlanInference(Network* net)
       CHECK_HIP(hipStreamSynchronize(st));
       a->dual_with = i + 2;
       b->dual_slave = 1;
+      a->dual_peer = b;
+      b->dual_peer = a;
     }
   }
   // 1c. fp16 path: pack the weights of the layers that take the direct fp16 kernel
@@ -406,12 +409,29 @@ void DkPlanInference(Network* net)
   // contain no tuning launches); written when absent.
   const char* tf = getenv("DK_TUNE_FILE");
   bool loaded = false;
+  // the cache is keyed on every conv descriptor, the plan flags and half mode (FNV-1a)
+  unsigned long long tkey = 1469598103934665603ULL;
+  auto mix = [&tkey](long long v) {
+    for (int k = 0; k < 8; ++k) { tkey ^= (unsigned long long)((v >> (8 * k)) & 0xff); tkey *= 1099511628211ULL; }
+  };
+  mix(net->n); mix(net->batch); mix(net->cudnn_half); mix(dk_conv_num_configs());
+  for (int i = 0; i < net->n; ++i)
+  {
+    const layer* l = &net->layers[i];
+    if (l->type != CONVOLUTIONAL)
+      continue;
+    for (long long v : {(long long)i, (long long)l->c, (long long)l->h, (long long)l->w, (long long)l->n, (long long)l->groups,
+             (long long)l->size, (long long)l->stride_x, (long long)l->stride_y, (long long)l->dilation, (long long)l->pad,
+             (long long)l->activation, (long long)(l->fuse_residual_from >= 0), (long long)l->dual_with, (long long)l->dual_slave})
+      mix(v);
+  }
   if (tune && tf)
   {
     if (FILE* f = fopen(tf, "r"))
     {
       int n = 0, b = 0;
-      if (fscanf(f, "%d %d", &n, &b) == 2 && n == net->n && b == net->batch)
+      unsigned long long k = 0;
+      if (fscanf(f, "%d %d %llu", &n, &b, &k) == 3 && n == net->n && b == net->batch && k == tkey)
       {
         loaded = true;
         for (int i = 0; i < net->n; ++i)
@@ -435,12 +455,13 @@ void DkPlanInference(Network* net)
     if (tf)
       if (FILE* f = fopen(tf, "w"))
       {
-        fprintf(f, "%d %d\n", net->n, net->batch);
+        fprintf(f, "%d %d %llu\n", net->n, net->batch, tkey);
         for (int i = 0; i < net->n; ++i) fprintf(f, "%d\n", net->layers[i].conv_cfg);
         fclose(f);
       }
   }
   DkInvalidateGraph(net);
+  net->planned = 1;
 }
 
 // ---------------------------------------------------------------------------

@@ -101,6 +101,13 @@ static void ParseNetOptions(Section& o, Network* net)
     net->step = FindOptionIntQuiet(o, "step", 1);
   }
   net->adam = FindOptionIntQuiet(o, "adam", 0);
+  if (net->adam)
+  {
+    // blas_kernels.cu:99-134 (adam_update_gpu) has no twin here yet: refuse instead of silently
+    // training with SGD + momentum
+    (void)FindOption(o, "B1"); (void)FindOption(o, "B2"); (void)FindOption(o, "eps");
+    error("adam=1 is not supported by the HIP path (only SGD with momentum); remove adam from [net]");
+  }
   net->loss_scale = FindOptionFloatQuiet(o, "loss_scale", 1);
   net->power = FindOptionFloatQuiet(o, "power", 4);
   net->workspace_size_limit =
@@ -109,7 +116,7 @@ static void ParseNetOptions(Section& o, Network* net)
   // as known so they do not show up as "Unused field".
   static const char* aug[] = {"max_crop", "min_crop", "flip", "blur", "gaussian_noise", "cutmix",
       "mosaic", "label_smooth_eps", "resize_step", "angle", "aspect", "saturation", "exposure",
-      "hue", "optimized_memory", "show_receptive_field", "B1", "B2", "eps"};
+      "hue", "optimized_memory", "show_receptive_field"};
   for (const char* k : aug) (void)FindOption(o, k);
 }
 
@@ -305,6 +312,8 @@ static void ParseRoute(layer* l, Section& o, SizeParams params)
 }
 
 // ---- ParseNetworkCfg ----------------------------------------------------------
+void DkConvPrepare(layer* l);
+
 static bool parse_cfg_batch(Network* net, char const* filename, bool train, int force_batch)
 {
   std::vector<Section> sections;
@@ -434,6 +443,11 @@ static bool parse_cfg_batch(Network* net, char const* filename, bool train, int 
         CHECK_HIP(hipMemsetAsync(net->delta_arena_gpu, 0, tot * sizeof(float), get_cuda_stream()));
       }
     }
+    // tap tables of every conv shape exist before anybody can capture a stream (train and
+    // inference loads alike: NetworkPredict on a train-mode or hand-assembled net captures too)
+    for (int i = 0; i < net->n; ++i)
+      if (net->layers[i].type == CONVOLUTIONAL)
+        DkConvPrepare(&net->layers[i]);
     CHECK_HIP(hipStreamSynchronize(get_cuda_stream()));
   }
   // host mirror of the last layer for NetworkPredict's return value
@@ -539,6 +553,7 @@ bool LoadWeightsUpTo(Network* net, char const* filename, int cutoff)
       break;
   }
   fclose(fp);
+  // PushConvolutionalLayer refreshed the derived copies (dual / packed fp16) layer by layer
   return true;
 }
 

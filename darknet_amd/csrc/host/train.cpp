@@ -291,14 +291,19 @@ static void backward_range(Network* net, NetworkState state, int hi, int lo)
   state.workspace = net->workspace;
   float* original_input = state.input;
   float* original_delta = state.delta;
+  // network_kernels.cu:140-143: a stopbackward layer ends the sweep FOR THE STEP; the flag makes
+  // that hold across the DkBackwardRange segments of the overlapped trainer too
+  if (net->backward_stopped)
+    return;
   for (int i = hi - 1; i >= lo; --i)
   {
     state.index = i;
     layer* l = &net->layers[i];
-    if (l->stopbackward == 1)
+    if (l->stopbackward == 1 || l->stopbackward > net->curr_iter)
+    {
+      net->backward_stopped = 1;
       break;
-    if (l->stopbackward > net->curr_iter)
-      break;
+    }
     if (i == 0)
     {
       state.input = original_input;
@@ -317,7 +322,11 @@ static void backward_range(Network* net, NetworkState state, int hi, int lo)
   }
 }
 
-void BackwardNetworkGpu(Network* net, NetworkState state) { backward_range(net, state, net->n, 0); }
+void BackwardNetworkGpu(Network* net, NetworkState state)
+{
+  net->backward_stopped = 0;
+  backward_range(net, state, net->n, 0);
+}
 
 extern "C" LIB_API size_t DkGradBucketSize(Network* net);
 
@@ -394,6 +403,7 @@ void DkTrainForward(Network* net, float* x, float* y)
   if (net->gpu_index < 0 || !net->train)
     error("DkTrainForward: needs a train-mode network on a HIP device");
   net->seen += net->batch;
+  net->backward_stopped = 0;
   const size_t x_size = (size_t)GetNetworkInputSize(net) * net->batch;
   memcpy(net->input_pinned_cpu, x, x_size * sizeof(float));
   cuda_push_array(net->input_state_gpu, net->input_pinned_cpu, x_size);

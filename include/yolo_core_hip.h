@@ -203,6 +203,7 @@ struct layer
   int dual_with;         /* index of the second conv, or 0 */
   int dual_slave;        /* 1: computed by an earlier layer's dual launch */
   float *dual_weights_gpu, *dual_biases_gpu;
+  struct layer* dual_peer; /* the other conv of a dual launch (master <-> slave), or NULL */
   void* weights_half_gpu; /* fp16 weights packed for conv3x3_direct_f16 (inference plan with cudnn_half), or NULL */
   int delta_in_arena;    /* delta_gpu points into net->delta_arena_gpu (not freed per layer) */
   float* out_view;       /* producer: where the output really goes (a channel slice), or NULL */
@@ -270,6 +271,8 @@ struct Network
   size_t delta_arena_size;
   float* grad_bucket;    /* caller-owned contiguous gradient bucket (DkAttachGradBucket), or NULL */
   int grad_replicas;     /* data-parallel replicas whose buckets are summed before the update (DkSetReplicas) */
+  int planned;           /* DkPlanInference ran (fusion plan, packed/dual weight copies exist) */
+  int backward_stopped;  /* train: a stopbackward layer ended this step's backward sweep (DkBackwardRange segments) */
 };
 
 #ifdef __cplusplus

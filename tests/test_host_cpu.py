@@ -197,3 +197,16 @@ def test_kernel_index_arithmetic_on_host(dk):
                 count[key] = count.get(key, 0) + 1
         assert len(count) == groups * tiles_m * tiles_n and set(count.values()) == {1}, (tiles_m, tiles_n, pm)
     assert {1, 2, 8} <= seen_pm
+
+
+def test_adam_cfg_is_refused_loudly(dk, tmp_path):
+    """adam=1 has no twin of adam_update_gpu (blas_kernels.cu:99-134) here: the parser must
+    exit with a message instead of silently training with SGD."""
+    src = open(netutil.cfg_path("yolov4-tiny")).read().replace("[net]", "[net]\nadam=1\nB1=0.9\nB2=0.999\neps=0.000001", 1)
+    cfg = tmp_path / "adam.cfg"
+    cfg.write_text(src)
+    code = ("import sys, ctypes as C; sys.path.insert(0, %r); import darknet_amd as dk; L = dk.lib(); "
+            "L.ParseNetworkCfg.restype = C.c_bool; L.ParseNetworkCfg.argtypes = [C.c_void_p, C.c_char_p, C.c_bool]; "
+            "L.ParseNetworkCfg(L.DkNetworkCreate(), %r.encode(), True)" % (ROOT, str(cfg)))
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"adam=1 is not supported" in r.stderr
