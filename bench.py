@@ -189,8 +189,8 @@ def main():
         prof_steps = 3
         for _ in range(prof_steps):
             step()
-        out = (C.c_double * (3 * 128))()
-        ncfg = L.dk_profile_read(out, 128)
+        out = (C.c_double * (3 * 256))()
+        ncfg = L.dk_profile_read(out, 256)
         L.dk_profile_enable(0)
         rows = [(out[3 * i + 2], out[3 * i], out[3 * i + 1], i) for i in range(ncfg) if out[3 * i] > 0]
         rows.sort(reverse=True)

@@ -10,6 +10,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #define DK_EXPORT extern "C" __attribute__((visibility("default")))
 
 int cuda_debug_sync = 0;
@@ -305,4 +309,19 @@ DK_EXPORT dim3 cuda_gridsize(size_t n)
 DK_EXPORT int get_number_of_blocks(int array_size, int block_size)
 {
   return array_size / block_size + ((array_size % block_size > 0) ? 1 : 0);
+}
+
+// ---- per-(device, kernel) dynamic-LDS limit (see dk_internal.h) --------------------------
+void dk_set_max_dynamic_lds(const void* kernel, int bytes)
+{
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, int> done;
+  int dev = 0;
+  CHECK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(mu);
+  int& have = done[std::make_pair(dev, kernel)];
+  if (have >= bytes)
+    return;
+  CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  have = bytes;
 }

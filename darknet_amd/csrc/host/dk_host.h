@@ -53,6 +53,7 @@ void FillRouteLayer(layer* l, int batch, int n, int* input_layers, int* input_si
 void FillShortcutLayer(layer* l, int batch, int index, int w, int h, int c, int from_outputs,
     ACTIVATION activation, int train);
 void FillUpsampleLayer(layer* l, int batch, int w, int h, int c, int stride);
+void FillDropoutLayer(layer* l, int batch, int inputs, float probability, int w, int h, int c);
 void FillYoloLayer(layer* l, int batch, int w, int h, int n, int total, int* mask, int classes,
     int max_boxes);
 

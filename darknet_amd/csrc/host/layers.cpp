@@ -673,9 +673,13 @@ void free_layer(layer* l, bool)
     cuda_free(l->dual_weights_gpu); cuda_free(l->dual_biases_gpu);
     cuda_free(l->biases_gpu); cuda_free(l->bias_updates_gpu);
     cuda_free(l->scales_gpu); cuda_free(l->scale_updates_gpu);
-    cuda_free(l->output_gpu); cuda_free(l->activation_input_gpu);
-    if (!l->delta_in_arena)
-      cuda_free(l->delta_gpu);
+    cuda_free(l->activation_input_gpu);
+    if (!l->buffers_aliased)
+    {
+      cuda_free(l->output_gpu);
+      if (!l->delta_in_arena)
+        cuda_free(l->delta_gpu);
+    }
   }
   memset(l, 0, sizeof(*l));
 }

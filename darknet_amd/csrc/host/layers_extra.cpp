@@ -1,0 +1,275 @@
+// layers_extra.cpp -- layer kinds used by sibling cfgs of the YOLOv4 family and
+// the remaining plugin symbols of the boundary: standalone [batchnorm], global
+// [avgpool], [scale_channels] (squeeze-and-excitation), [dropout] at inference, backward_bias_gpu,
+// the upstream-darknet aliases and init_cpu.
+//
+// Reference twins (Ravicmoon/darknet src/): FillBatchnormLayer batchnorm_layer.cpp:9-88,
+// Forward/Backward/UpdateBatchnormLayerGpu :268-409 (numerics of the CPU twins :206-266: variance
+// over N-1, eps 1e-6 forward / 1e-5 backward, rolling .9/.1); FillAvgpoolLayer avgpool_layer.cpp:6-40,
+// ForwardAvgpoolLayerGpu avgpool_layer_kernels.cu:46-62; FillScaleChannelsLayer
+// scale_channels_layer.c:9-48, Forward/BackwardScaleChannelsLayerGpu :129-160; ParseDropout
+// parser.cpp:672-712 + the aliasing of its buffers :1232-1242; backward_bias_gpu
+// convolutional_kernels.cu:37-67 (declared convolutional_layer.h:14); init_cpu utils.cpp.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "dk_host.h"
+#include "dk_internal.h"
+
+extern "C" {
+int dk_bn_forward_train(const float*, float*, float*, float*, float*, float*, float*, float*, float*,
+    const float*, const float*, int, int, int, int, int, void*);
+}
+
+static void no_cpu_path(layer* l, NetworkState)
+{
+  fprintf(stderr, "darknet_amd: layer %d has no CPU compute path (HIP path only, no fallback)\n", l->index);
+  exit(EXIT_FAILURE);
+}
+
+// ---------------------------------------------------------------- [batchnorm]
+void FillBatchnormLayer(layer* l, int batch, int w, int h, int c, int train)
+{
+  l->type = BATCHNORM;
+  l->batch = batch;
+  l->train = train;
+  l->h = l->out_h = h;
+  l->w = l->out_w = w;
+  l->c = l->out_c = c;
+  l->n = c;
+  l->inputs = w * h * c;
+  l->outputs = l->inputs;
+  l->activation = LINEAR;
+  l->biases = (float*)xcalloc(c, sizeof(float));
+  l->bias_updates = (float*)xcalloc(c, sizeof(float));
+  l->scales = (float*)xcalloc(c, sizeof(float));
+  l->scale_updates = (float*)xcalloc(c, sizeof(float));
+  for (int i = 0; i < c; ++i) l->scales[i] = 1;
+  l->mean = (float*)xcalloc(c, sizeof(float));
+  l->variance = (float*)xcalloc(c, sizeof(float));
+  l->rolling_mean = (float*)xcalloc(c, sizeof(float));
+  l->rolling_variance = (float*)xcalloc(c, sizeof(float));
+  l->forward = no_cpu_path;
+  l->backward = no_cpu_path;
+  l->forward_gpu = ForwardBatchnormLayerGpu;
+  l->backward_gpu = BackwardBatchnormLayerGpu;
+  l->update_gpu = UpdateBatchnormLayerGpu;
+  if (dk_gpu_enabled())
+  {
+    const size_t total = (size_t)batch * l->outputs;
+    l->output_gpu = cuda_make_array(nullptr, total);
+    l->biases_gpu = cuda_make_array(l->biases, c);
+    l->scales_gpu = cuda_make_array(l->scales, c);
+    l->mean_gpu = cuda_make_array(l->mean, c);
+    l->variance_gpu = cuda_make_array(l->variance, c);
+    l->rolling_mean_gpu = cuda_make_array(l->mean, c);
+    l->rolling_variance_gpu = cuda_make_array(l->variance, c);
+    if (train)
+    {
+      l->delta_gpu = cuda_make_array(nullptr, total);
+      CHECK_HIP(hipMemsetAsync(l->delta_gpu, 0, total * sizeof(float), get_cuda_stream()));
+      l->bias_updates_gpu = cuda_make_array(l->bias_updates, c);
+      l->scale_updates_gpu = cuda_make_array(l->scale_updates, c);
+      l->mean_delta_gpu = cuda_make_array(l->mean, c);
+      l->variance_delta_gpu = cuda_make_array(l->variance, c);
+      l->x_gpu = cuda_make_array(nullptr, total);
+      l->x_norm_gpu = cuda_make_array(nullptr, total);
+    }
+  }
+}
+
+void ForwardBatchnormLayerGpu(layer* l, NetworkState state)
+{
+  // one pass: statistics (train) -> normalise, scale, bias; x / x_norm saved for the backward pass
+  const int train = state.train && l->x_gpu && l->x_norm_gpu;
+  if (dk_bn_forward_train(state.input, l->x_gpu, l->x_norm_gpu, nullptr, l->output_gpu, l->mean_gpu,
+          l->variance_gpu, l->rolling_mean_gpu, l->rolling_variance_gpu, l->scales_gpu, l->biases_gpu,
+          l->batch, l->out_c, l->out_h * l->out_w, (int)LINEAR, train, get_cuda_stream()))
+    error("ForwardBatchnormLayerGpu failed");
+}
+
+void BackwardBatchnormLayerGpu(layer* l, NetworkState state)
+{
+  hipStream_t st = get_cuda_stream();
+  if (!state.train)
+  {
+    // batchnorm_layer.cpp:326-335: statistics of an inference-mode backward = the rolling ones
+    dk_copy(l->out_c, l->rolling_mean_gpu, l->mean_gpu, st);
+    dk_copy(l->out_c, l->rolling_variance_gpu, l->variance_gpu, st);
+  }
+  if (dk_bn_backward(l->delta_gpu, l->x_gpu, l->x_norm_gpu, l->mean_gpu, l->variance_gpu, l->scales_gpu,
+          l->mean_delta_gpu, l->variance_delta_gpu, l->scale_updates_gpu, l->bias_updates_gpu, l->batch,
+          l->out_c, l->out_h * l->out_w, st))
+    error("BackwardBatchnormLayerGpu failed");
+  if (l->type == BATCHNORM && state.delta)
+    dk_copy((size_t)l->outputs * l->batch, l->delta_gpu, state.delta, st);
+}
+
+void UpdateBatchnormLayerGpu(layer* l, int batch, float learning_rate_init, float momentum, float decay,
+    float loss_scale)
+{
+  (void)decay;
+  hipStream_t st = get_cuda_stream();
+  const float lr = learning_rate_init * l->learning_rate_scale / loss_scale;
+  dk_sgd_update(l->biases_gpu, l->bias_updates_gpu, l->c, batch, lr, momentum, 0.f, 0, st);
+  dk_sgd_update(l->scales_gpu, l->scale_updates_gpu, l->c, batch, lr, momentum, 0.f, 0, st);
+}
+
+void PushBatchnormLayer(layer* l)
+{
+  if (!dk_gpu_enabled())
+    return;
+  cuda_push_array(l->biases_gpu, l->biases, l->out_c);
+  cuda_push_array(l->scales_gpu, l->scales, l->out_c);
+  cuda_push_array(l->rolling_mean_gpu, l->rolling_mean, l->out_c);
+  cuda_push_array(l->rolling_variance_gpu, l->rolling_variance, l->out_c);
+  CHECK_HIP(hipStreamSynchronize(get_cuda_stream()));
+}
+
+void PullBatchnormLayer(layer* l)
+{
+  if (!dk_gpu_enabled())
+    return;
+  cuda_pull_array(l->biases_gpu, l->biases, l->out_c);
+  cuda_pull_array(l->scales_gpu, l->scales, l->out_c);
+  cuda_pull_array(l->rolling_mean_gpu, l->rolling_mean, l->out_c);
+  cuda_pull_array(l->rolling_variance_gpu, l->rolling_variance, l->out_c);
+}
+
+// ------------------------------------------------------------------ [avgpool]
+void FillAvgpoolLayer(layer* l, int batch, int w, int h, int c)
+{
+  l->type = AVGPOOL;
+  l->batch = batch;
+  l->h = h; l->w = w; l->c = c;
+  l->out_w = 1; l->out_h = 1; l->out_c = c;
+  l->outputs = l->out_c;
+  l->inputs = h * w * c;
+  l->forward = no_cpu_path;
+  l->backward = no_cpu_path;
+  l->forward_gpu = ForwardAvgpoolLayerGpu;
+  l->backward_gpu = BackwardAvgpoolLayerGpu;
+  if (dk_gpu_enabled())
+  {
+    const size_t total = (size_t)l->outputs * batch;
+    l->output_gpu = cuda_make_array(nullptr, total);
+    l->delta_gpu = cuda_make_array(nullptr, total);
+    CHECK_HIP(hipMemsetAsync(l->delta_gpu, 0, total * sizeof(float), get_cuda_stream()));
+  }
+}
+
+void ForwardAvgpoolLayerGpu(layer* l, NetworkState state)
+{
+  if (dk_avgpool_forward(state.input, l->output_gpu, l->batch, l->c, l->h, l->w, get_cuda_stream()))
+    error("ForwardAvgpoolLayerGpu failed");
+}
+
+void BackwardAvgpoolLayerGpu(layer* l, NetworkState state)
+{
+  if (!state.delta)
+    return;
+  if (dk_avgpool_backward(l->delta_gpu, state.delta, l->batch, l->c, l->h, l->w, get_cuda_stream()))
+    error("BackwardAvgpoolLayerGpu failed");
+}
+
+// ----------------------------------------------------------- [scale_channels]
+void FillScaleChannelsLayer(layer* l, int batch, int index, int w, int h, int c, int w2, int h2, int c2,
+    int scale_wh)
+{
+  l->type = SCALE_CHANNELS;
+  l->batch = batch;
+  l->scale_wh = scale_wh;
+  l->w = w; l->h = h; l->c = c;
+  if (!scale_wh && !(w == 1 && h == 1))
+    error("[scale_channels]: the scale tensor must be 1 x 1 x c (put an [avgpool] before it)");
+  if (scale_wh && c != 1)
+    error("[scale_channels] scale_wh=1: the scale tensor must have one channel");
+  l->out_w = w2; l->out_h = h2; l->out_c = c2;
+  if (!scale_wh && l->out_c != l->c)
+    error("[scale_channels]: channel counts differ");
+  if (scale_wh && !(l->out_w == l->w && l->out_h == l->h))
+    error("[scale_channels] scale_wh=1: spatial sizes differ");
+  l->outputs = l->out_w * l->out_h * l->out_c;
+  l->inputs = l->outputs;
+  l->index = index;
+  l->activation = LINEAR;
+  l->forward = no_cpu_path;
+  l->backward = no_cpu_path;
+  l->forward_gpu = ForwardScaleChannelsLayerGpu;
+  l->backward_gpu = BackwardScaleChannelsLayerGpu;
+  if (dk_gpu_enabled())
+  {
+    const size_t total = (size_t)l->outputs * batch;
+    l->output_gpu = cuda_make_array(nullptr, total);
+    l->delta_gpu = cuda_make_array(nullptr, total);
+    CHECK_HIP(hipMemsetAsync(l->delta_gpu, 0, total * sizeof(float), get_cuda_stream()));
+  }
+}
+
+void ForwardScaleChannelsLayerGpu(layer* l, NetworkState state)
+{
+  const layer* from = &state.net->layers[l->index];
+  if (dk_scale_channels_forward(state.input, DkLayerOut(from), l->output_gpu, l->batch, l->out_c, l->out_h,
+          l->out_w, l->scale_wh, (int)l->activation, get_cuda_stream()))
+    error("ForwardScaleChannelsLayerGpu failed");
+}
+
+void BackwardScaleChannelsLayerGpu(layer* l, NetworkState state)
+{
+  hipStream_t st = get_cuda_stream();
+  dk_gradient_array(l->output_gpu, nullptr, l->delta_gpu, (size_t)l->outputs * l->batch, (int)l->activation, st);
+  layer* from = &state.net->layers[l->index];
+  if (dk_scale_channels_backward(l->delta_gpu, state.input, from->output_gpu, from->delta_gpu, state.delta,
+          l->batch, l->out_c, l->out_h, l->out_w, l->scale_wh, st))
+    error("BackwardScaleChannelsLayerGpu failed");
+}
+
+// ------------------------------------------------------------------ [dropout]
+// Inference: identity; the layer aliases its predecessor's buffers exactly as the reference
+// does (parser.cpp:1232-1242).  Training needs the reference's cuRAND stream to be reproduced
+// and is outside the hot path: refused loudly.
+static void forward_dropout_gpu(layer* l, NetworkState state)
+{
+  if (state.train)
+    error("[dropout] in train mode is outside the supported hot path (needs the reference's RNG stream)");
+  (void)l;
+}
+static void backward_dropout_gpu(layer*, NetworkState) { error("[dropout] backward is outside the supported hot path"); }
+
+void FillDropoutLayer(layer* l, int batch, int inputs, float probability, int w, int h, int c)
+{
+  l->type = DROPOUT;
+  l->probability = probability;
+  l->inputs = inputs;
+  l->outputs = inputs;
+  l->batch = batch;
+  l->out_w = l->w = w;
+  l->out_h = l->h = h;
+  l->out_c = l->c = c;
+  l->scale = 1. / (1. - probability);
+  l->forward = no_cpu_path;
+  l->backward = no_cpu_path;
+  l->forward_gpu = forward_dropout_gpu;
+  l->backward_gpu = backward_dropout_gpu;
+  l->buffers_aliased = 1;  // output_gpu / delta_gpu belong to the previous layer (set by the parser)
+}
+
+// ---------------------------------------------------------------- boundary odds and ends
+void backward_bias_gpu(float* bias_updates, float* delta, int batch, int n, int size)
+{
+  dk_backward_bias(bias_updates, delta, batch, n, size, nullptr);
+}
+
+// upstream darknet spellings of the conv slots (BASELINE north_star names them)
+void forward_convolutional_layer_gpu(layer* l, NetworkState state) { ForwardConvolutionalLayerGpu(l, state); }
+void backward_convolutional_layer_gpu(layer* l, NetworkState state) { BackwardConvolutionalLayerGpu(l, state); }
+void update_convolutional_layer_gpu(layer* l, int batch, float learning_rate, float momentum, float decay,
+    float loss_scale)
+{
+  UpdateConvolutionalLayerGpu(l, batch, learning_rate, momentum, decay, loss_scale);
+}
+
+// The reference's init_cpu probes AVX/FMA for its CPU GEMM (utils.cpp / gemm.c); this library has no
+// CPU compute path, so there is nothing to initialise.
+void init_cpu(void) {}

@@ -36,6 +36,12 @@ void DkSetAutotune(int on) { g_dk_autotune = on; }
 int g_dk_half = -1;
 void DkSetHalf(int on) { g_dk_half = on; }
 extern "C" LIB_API void DkSetPullHeads(int on) { g_dk_pull_heads = on; }
+// per-network overrides (stored +1; 0 = follow the process-wide setting)
+void DkNetSetGraph(Network* net, int on) { net->opt_graph = on < 0 ? 0 : (on ? 2 : 1); }
+void DkNetSetPullHeads(Network* net, int on) { net->opt_pull_heads = on < 0 ? 0 : (on ? 2 : 1); }
+static bool net_graph(const Network* net) { return net->opt_graph ? net->opt_graph == 2 : g_dk_graph != 0; }
+static bool net_pull_heads(const Network* net) { return net->opt_pull_heads ? net->opt_pull_heads == 2 : g_dk_pull_heads != 0; }
+void DkFreeDpState(Network* net);
 
 // ---------------------------------------------------------------------------
 int GetNetworkInputSize(Network* net) { return net->layers[0].inputs; }
@@ -124,7 +130,7 @@ static bool output_referenced_elsewhere(Network* net, int idx, int except_layer)
       for (int k = 0; k < l->n; ++k)
         if (l->input_layers[k] == idx)
           return true;
-    if (l->type == SHORTCUT && l->index == idx)
+    if ((l->type == SHORTCUT || l->type == SCALE_CHANNELS) && l->index == idx)
       return true;
   }
   return false;
@@ -290,7 +296,7 @@ void DkPlanInference(Network* net)
       {
         if (i > 0)
           readers[i - 1]++;  // every other layer kind reads its predecessor
-        if (l->type == SHORTCUT)
+        if (l->type == SHORTCUT || l->type == SCALE_CHANNELS)
           readers[l->index]++;
       }
     }
@@ -501,17 +507,16 @@ void ForwardNetworkGpu(Network* net, NetworkState state)
   }
 }
 
-static hipEvent_t g_fwd_done[16], g_copy_done[16];
-static int g_ev_init[16];
-static int g_copy_pending[16];
-
-static void ensure_events(int dev)
+// the events live in the Network (one thread per network may run predictions concurrently)
+static void ensure_events(Network* net)
 {
-  if (!g_ev_init[dev])
+  if (!net->fwd_done_ev)
   {
-    CHECK_HIP(hipEventCreateWithFlags(&g_fwd_done[dev], hipEventDisableTiming));
-    CHECK_HIP(hipEventCreateWithFlags(&g_copy_done[dev], hipEventDisableTiming));
-    g_ev_init[dev] = 1;
+    hipEvent_t a, b;
+    CHECK_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+    CHECK_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+    net->fwd_done_ev = a;
+    net->copy_done_ev = b;
   }
 }
 
@@ -523,8 +528,7 @@ void NetworkPredictDevice(Network* net, float* input_gpu)
     error("NetworkPredictDevice: network was loaded without a HIP device (no CPU fallback)");
   if (net->gpu_index != cuda_get_device())
     cuda_set_device(net->gpu_index);
-  const int dev = net->gpu_index;
-  ensure_events(dev);
+  ensure_events(net);
   hipStream_t st = get_cuda_stream();
   net->predict_seq++;
   NetworkState state;
@@ -534,13 +538,13 @@ void NetworkPredictDevice(Network* net, float* input_gpu)
   state.train = 0;
 
   // the previous call's head copies must finish before the heads are rewritten
-  if (g_copy_pending[dev])
+  if (net->copy_pending)
   {
-    CHECK_HIP(hipStreamWaitEvent(st, g_copy_done[dev], 0));
-    g_copy_pending[dev] = 0;
+    CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)net->copy_done_ev, 0));
+    net->copy_pending = 0;
   }
 
-  const bool can_graph = g_dk_graph && !net->benchmark_layers && !net->wait_stream &&
+  const bool can_graph = net_graph(net) && !net->benchmark_layers && !net->wait_stream &&
                          !dk_profile_is_on() && state.input == net->input_state_gpu;
   if (can_graph)
   {
@@ -560,13 +564,13 @@ void NetworkPredictDevice(Network* net, float* input_gpu)
   else
     ForwardNetworkGpu(net, state);
 
-  if (g_dk_pull_heads)
+  if (net_pull_heads(net))
   {
     // yolo heads -> pinned host memory on the copy stream (the reference pulls
     // them asynchronously inside ForwardYoloLayerGpu, yolo_layer.cpp:854-858)
     hipStream_t cs = get_cuda_memcpy_stream();
-    CHECK_HIP(hipEventRecord(g_fwd_done[dev], st));
-    CHECK_HIP(hipStreamWaitEvent(cs, g_fwd_done[dev], 0));
+    CHECK_HIP(hipEventRecord((hipEvent_t)net->fwd_done_ev, st));
+    CHECK_HIP(hipStreamWaitEvent(cs, (hipEvent_t)net->fwd_done_ev, 0));
     for (int i = 0; i < net->n; ++i)
     {
       layer* l = &net->layers[i];
@@ -574,8 +578,8 @@ void NetworkPredictDevice(Network* net, float* input_gpu)
         CHECK_HIP(hipMemcpyAsync(l->output, l->output_gpu,
             (size_t)l->batch * l->outputs * sizeof(float), hipMemcpyDeviceToHost, cs));
     }
-    CHECK_HIP(hipEventRecord(g_copy_done[dev], cs));
-    g_copy_pending[dev] = 1;
+    CHECK_HIP(hipEventRecord((hipEvent_t)net->copy_done_ev, cs));
+    net->copy_pending = 1;
   }
 }
 
@@ -597,7 +601,7 @@ float* GetNetworkOutputGpu(Network* net)
       break;
   layer* l = &net->layers[i];
   NetworkSync(net);
-  if (l->type != YOLO || !g_dk_pull_heads)
+  if (l->type != YOLO || !net_pull_heads(net))
     cuda_pull_array(l->output_gpu, l->output, (size_t)l->outputs * l->batch);
   return l->output;
 }
@@ -788,7 +792,7 @@ static int candidates_to_dets(Network* net, int b, float thresh, Detection* dets
   return out;
 }
 
-static bool heads_on_device(Network* net) { return !g_dk_pull_heads && net->gpu_index >= 0; }
+static bool heads_on_device(Network* net) { return !net_pull_heads(net) && net->gpu_index >= 0; }
 
 static int num_detections(Network* net, int b, float thresh)
 {
@@ -943,10 +947,16 @@ void FreeNetwork(Network* net)
     for (int i = 0; i < net->n; ++i)
     {
       layer* l = &net->layers[i];
-      if (l->type == CONVOLUTIONAL)
+      if (l->type == CONVOLUTIONAL || l->type == BATCHNORM)
         l->weight_updates_gpu = l->bias_updates_gpu = l->scale_updates_gpu = nullptr;
     }
   for (int i = 0; i < net->n; ++i) free_layer(&net->layers[i], false);
+  if (net->gpu_index >= 0)
+  {
+    DkFreeDpState(net);
+    if (net->fwd_done_ev) (void)hipEventDestroy((hipEvent_t)net->fwd_done_ev);
+    if (net->copy_done_ev) (void)hipEventDestroy((hipEvent_t)net->copy_done_ev);
+  }
   free(net->layers);
   free(net->steps);
   free(net->scales);

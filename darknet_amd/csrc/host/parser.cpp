@@ -311,7 +311,84 @@ static void ParseRoute(layer* l, Section& o, SizeParams params)
   l->c = l->out_c;
 }
 
+static void ParseBatchnorm(layer* l, Section&, SizeParams params)
+{
+  FillBatchnormLayer(l, params.batch, params.w, params.h, params.c, params.train);
+}
+
+static void ParseAvgpool(layer* l, Section&, SizeParams params)
+{
+  if (!(params.h && params.w && params.c))
+    error("Layer before avgpool layer must output image.");
+  FillAvgpoolLayer(l, params.batch, params.w, params.h, params.c);
+}
+
+static void ParseScaleChannels(layer* l, Section& o, SizeParams params, Network* net)
+{
+  const char* from = FindOption(o, "from");
+  if (!from)
+    error("[scale_channels] must specify from = ...");
+  int idx = atoi(from);
+  if (idx < 0)
+    idx = params.index + idx;
+  if (idx < 0 || idx >= params.index)
+    error("[scale_channels] from= out of range");
+  const int scale_wh = FindOptionIntQuiet(o, "scale_wh", 0);
+  layer* f = &net->layers[idx];
+  FillScaleChannelsLayer(l, params.batch, idx, params.w, params.h, params.c, f->out_w, f->out_h, f->out_c, scale_wh);
+  l->activation = get_activation(FindOptionStrQuiet(o, "activation", "linear"));
+  if (l->activation == SWISH || l->activation == MISH)
+    printf(" [scale_channels] layer doesn't support SWISH or MISH activations \n");
+}
+
+static void ParseDropout(layer* l, Section& o, SizeParams params, Network* net)
+{
+  const float probability = FindOptionFloat(o, "probability", .2);
+  if (FindOptionIntQuiet(o, "dropblock", 0))
+    error("[dropout] dropblock is outside the supported hot path");
+  (void)FindOption(o, "dropblock_size_rel");
+  (void)FindOption(o, "dropblock_size_abs");
+  if (params.index < 1)
+    error("[dropout] cannot be the first layer");
+  FillDropoutLayer(l, params.batch, params.inputs, probability, params.w, params.h, params.c);
+  // parser.cpp:1232-1242: the layer works in place on its predecessor's buffers
+  layer* prev = &net->layers[params.index - 1];
+  l->output_gpu = prev->output_gpu;
+  l->delta_gpu = prev->delta_gpu;
+}
+
 // ---- ParseNetworkCfg ----------------------------------------------------------
+// One arena for all delta tensors: the per-layer zero-fills of the forward pass
+// (forward_network_gpu's fill_ongpu per layer, network_kernels.cu:79) become one memset.
+void DkBuildDeltaArena(Network* net)
+{
+  size_t tot = 0;
+  for (int i = 0; i < net->n; ++i)
+    if (net->layers[i].delta_gpu && !net->layers[i].buffers_aliased)
+      tot += (((size_t)net->layers[i].outputs * net->layers[i].batch + 63) / 64) * 64;
+  if (!tot)
+    return;
+  net->delta_arena_gpu = cuda_make_array(0, tot);
+  net->delta_arena_size = tot;
+  size_t off = 0;
+  for (int i = 0; i < net->n; ++i)
+  {
+    layer* l = &net->layers[i];
+    if (l->buffers_aliased)
+    {
+      l->delta_gpu = net->layers[i - 1].delta_gpu;   // follows its predecessor into the arena
+      continue;
+    }
+    if (!l->delta_gpu)
+      continue;
+    cuda_free(l->delta_gpu);
+    l->delta_gpu = net->delta_arena_gpu + off;
+    l->delta_in_arena = 1;
+    off += (((size_t)l->outputs * l->batch + 63) / 64) * 64;
+  }
+  CHECK_HIP(hipMemsetAsync(net->delta_arena_gpu, 0, tot * sizeof(float), get_cuda_stream()));
+}
+
 void DkConvPrepare(layer* l);
 
 static bool parse_cfg_batch(Network* net, char const* filename, bool train, int force_batch)
@@ -367,6 +444,14 @@ static bool parse_cfg_batch(Network* net, char const* filename, bool train, int 
       ParseShortcut(l, s, params, net);
     else if (s.type == "[upsample]")
       ParseUpsample(l, s, params);
+    else if (s.type == "[batchnorm]")
+      ParseBatchnorm(l, s, params);
+    else if (s.type == "[avgpool]" || s.type == "[avg]")
+      ParseAvgpool(l, s, params);
+    else if (s.type == "[scale_channels]")
+      ParseScaleChannels(l, s, params, net);
+    else if (s.type == "[dropout]")
+      ParseDropout(l, s, params, net);
     else
     {
       fprintf(stderr, "Type is not recognized: %s\n", s.type.c_str());
@@ -419,29 +504,7 @@ static bool parse_cfg_batch(Network* net, char const* filename, bool train, int 
         if (net->layers[i].type == CONVOLUTIONAL && (size_t)net->layers[i].nweights > maxw)
           maxw = net->layers[i].nweights;
       net->wt_scratch_gpu = cuda_make_array(0, maxw);
-      // one arena for all delta tensors: the per-layer zero-fills of the forward pass
-      // (forward_network_gpu's fill_ongpu per layer, network_kernels.cu:79) become one memset
-      size_t tot = 0;
-      for (int i = 0; i < net->n; ++i)
-        if (net->layers[i].delta_gpu)
-          tot += (((size_t)net->layers[i].outputs * net->layers[i].batch + 63) / 64) * 64;
-      if (tot)
-      {
-        net->delta_arena_gpu = cuda_make_array(0, tot);
-        net->delta_arena_size = tot;
-        size_t off = 0;
-        for (int i = 0; i < net->n; ++i)
-        {
-          layer* l = &net->layers[i];
-          if (!l->delta_gpu)
-            continue;
-          cuda_free(l->delta_gpu);
-          l->delta_gpu = net->delta_arena_gpu + off;
-          l->delta_in_arena = 1;
-          off += (((size_t)l->outputs * l->batch + 63) / 64) * 64;
-        }
-        CHECK_HIP(hipMemsetAsync(net->delta_arena_gpu, 0, tot * sizeof(float), get_cuda_stream()));
-      }
+      DkBuildDeltaArena(net);
     }
     // tap tables of every conv shape exist before anybody can capture a stream (train and
     // inference loads alike: NetworkPredict on a train-mode or hand-assembled net captures too)
@@ -478,6 +541,26 @@ static void SaveConvolutionalWeights(layer* l, FILE* fp)
   fwrite(l->weights, sizeof(float), l->nweights, fp);
 }
 
+// parser.cpp:1562-1572 / :1683-1693
+static void SaveBatchnormWeights(layer* l, FILE* fp)
+{
+  if (dk_gpu_enabled())
+    PullBatchnormLayer(l);
+  fwrite(l->biases, sizeof(float), l->c, fp);
+  fwrite(l->scales, sizeof(float), l->c, fp);
+  fwrite(l->rolling_mean, sizeof(float), l->c, fp);
+  fwrite(l->rolling_variance, sizeof(float), l->c, fp);
+}
+
+static void LoadBatchnormWeights(layer* l, FILE* fp)
+{
+  fread(l->biases, sizeof(float), l->c, fp);
+  fread(l->scales, sizeof(float), l->c, fp);
+  fread(l->rolling_mean, sizeof(float), l->c, fp);
+  fread(l->rolling_variance, sizeof(float), l->c, fp);
+  PushBatchnormLayer(l);
+}
+
 void SaveWeightsUpto(Network* net, char const* filename, int cutoff)
 {
   if (net->gpu_index >= 0 && net->layers && dk_gpu_enabled())
@@ -495,6 +578,8 @@ void SaveWeightsUpto(Network* net, char const* filename, int cutoff)
     layer* l = &net->layers[i];
     if (l->type == CONVOLUTIONAL && l->share_layer == NULL)
       SaveConvolutionalWeights(l, fp);
+    if (l->type == BATCHNORM)
+      SaveBatchnormWeights(l, fp);
   }
   fclose(fp);
 }
@@ -549,6 +634,8 @@ bool LoadWeightsUpTo(Network* net, char const* filename, int cutoff)
       continue;
     if (l->type == CONVOLUTIONAL && l->share_layer == NULL)
       LoadConvolutionalWeights(l, fp);
+    if (l->type == BATCHNORM)
+      LoadBatchnormWeights(l, fp);
     if (feof(fp))
       break;
   }
@@ -570,6 +657,8 @@ size_t DkWeightsFileSize(Network* net)
     layer* l = &net->layers[i];
     if (l->type == CONVOLUTIONAL)
       n += sizeof(float) * ((size_t)l->n + l->nweights + (l->batch_normalize ? 3 * (size_t)l->n : 0));
+    if (l->type == BATCHNORM)
+      n += sizeof(float) * 4 * (size_t)l->c;
   }
   return n;
 }

@@ -333,7 +333,8 @@ extern "C" LIB_API size_t DkGradBucketSize(Network* net);
 void UpdateNetworkGpu(Network* net)
 {
   cuda_set_device(net->gpu_index);
-  const int actual_batch = net->batch * net->subdiv;
+  // B = images behind the accumulated gradients: sub-batches of this replica x data-parallel replicas
+  const int actual_batch = net->batch * net->subdiv * (net->grad_replicas > 1 ? net->grad_replicas : 1);
   const int iter = net->curr_iter;
   const float lr = GetCurrLr(net);
   for (int i = 0; i < net->n; ++i)
@@ -499,8 +500,10 @@ extern "C" LIB_API size_t DkGradBucketSize(Network* net)
   for (int i = 0; i < net->n; ++i)
   {
     layer* l = &net->layers[i];
-    if (l->type == CONVOLUTIONAL && l->weight_updates_gpu)
-      n += (size_t)l->nweights + l->n + (l->scale_updates_gpu ? l->n : 0);
+    if (l->type == CONVOLUTIONAL && (l->weight_updates_gpu || l->weight_updates))
+      n += (size_t)l->nweights + l->n + ((l->scale_updates_gpu || l->scale_updates) ? l->n : 0);
+    if (l->type == BATCHNORM && (l->scale_updates_gpu || (l->train && l->scale_updates)))
+      n += 2 * (size_t)l->c;
   }
   return n;
 }
@@ -521,6 +524,12 @@ extern "C" LIB_API void DkAttachGradBucket(Network* net, float* bucket)
   for (int i = 0; i < net->n; ++i)
   {
     layer* l = &net->layers[i];
+    if (l->type == BATCHNORM && l->scale_updates_gpu)
+    {
+      move(&l->bias_updates_gpu, l->c);
+      move(&l->scale_updates_gpu, l->c);
+      continue;
+    }
     if (l->type != CONVOLUTIONAL || !l->weight_updates_gpu)
       continue;
     move(&l->weight_updates_gpu, l->nweights);
@@ -531,23 +540,20 @@ extern "C" LIB_API void DkAttachGradBucket(Network* net, float* bucket)
   net->grad_bucket = bucket;
 }
 
-// B = batch * subdivisions in the update; with R replicas set subdivisions = R
-// (each replica contributes one sub-batch, exactly the reference's accumulation
-// over subdivisions).
+// B = batch * subdivisions * replicas in the update (each replica contributes its sub-batches,
+// exactly the reference's accumulation over subdivisions).
 extern "C" LIB_API void DkSetSubdivisions(Network* net, int subdiv) { net->subdiv = subdiv; }
-extern "C" LIB_API void DkSetReplicas(Network* net, int replicas)
-{
-  net->subdiv = replicas;
-  net->grad_replicas = replicas;
-}
+extern "C" LIB_API void DkSetReplicas(Network* net, int replicas) { net->grad_replicas = replicas; }
 extern "C" LIB_API size_t DkGradBucketOffset(Network* net, int upto)
 {
   size_t n = 0;
   for (int i = 0; i < net->n && i < upto; ++i)
   {
     layer* l = &net->layers[i];
-    if (l->type == CONVOLUTIONAL && l->weight_updates_gpu)
-      n += (size_t)l->nweights + l->n + (l->scale_updates_gpu ? l->n : 0);
+    if (l->type == CONVOLUTIONAL && (l->weight_updates_gpu || l->weight_updates))
+      n += (size_t)l->nweights + l->n + ((l->scale_updates_gpu || l->scale_updates) ? l->n : 0);
+    if (l->type == BATCHNORM && (l->scale_updates_gpu || (l->train && l->scale_updates)))
+      n += 2 * (size_t)l->c;
   }
   return n;
 }

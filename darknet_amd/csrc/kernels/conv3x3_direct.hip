@@ -39,6 +39,12 @@
 #define DK_DIRECT_MIDSTORE 11
 #endif
 
+// diagnostic ablation builds: see conv_igemm.hip (DK_ABL bits: 0 epilogue, 1 LDS staging writes,
+// 2 global loads, 3 barriers, 4 LDS fragment reads)
+#ifndef DK_ABL
+#define DK_ABL 0
+#endif
+
 namespace
 {
 constexpr int CK = 4;        // channels per K stage
@@ -176,6 +182,14 @@ conv3x3_direct_f32(const ConvArgs p)
     float rp[CK * NJ];
 
     auto load_stage = [&](int st) {
+      if (DK_ABL & 4)
+      {
+#pragma unroll
+        for (int j = 0; j < PA * 4; ++j) ra[j] = (float)(st + j);
+#pragma unroll
+        for (int j = 0; j < CK * NJ; ++j) rp[j] = (float)(st - j);
+        return;
+      }
       const int ak = st * (KS * 4);  // byte offset of the stage inside a weight row
 #pragma unroll
       for (int jj = 0; jj < PA; ++jj)
@@ -198,6 +212,14 @@ conv3x3_direct_f32(const ConvArgs p)
     };
 
     auto store_stage = [&](float* stg) {
+      if (DK_ABL & 2)
+      {
+#pragma unroll
+        for (int j = 0; j < PA * 4; ++j) asm volatile("" ::"v"(ra[j]));
+#pragma unroll
+        for (int j = 0; j < CK * NJ; ++j) asm volatile("" ::"v"(rp[j]));
+        return;
+      }
       float* As = stg;
       float* Ps = stg + A_FLOATS;
 #pragma unroll
@@ -217,7 +239,8 @@ conv3x3_direct_f32(const ConvArgs p)
 
     load_stage(0);
     store_stage(lds);
-    __syncthreads();
+    if (!(DK_ABL & 8))
+      __syncthreads();
 
     for (int st = 0; st < nst; ++st)
     {
@@ -242,10 +265,20 @@ conv3x3_direct_f32(const ConvArgs p)
         const int dd = tap_off<P, CAP>(2 * s + 1) - o0;
         const int x = (dd == D1) ? 0 : (dd == D2) ? 1 : 2;
         float a[TM], b[TN];
+        if (DK_ABL & 16)
+        {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) a[i] = (float)(lane + i + s);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) b[j] = (float)(lane - j - s);
+        }
+        else
+        {
 #pragma unroll
         for (int i = 0; i < TM; ++i) a[i] = As[i * 32 * AS + 2 * s];
 #pragma unroll
         for (int j = 0; j < TN; ++j) b[j] = pj[j][x][o0];
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -263,7 +296,8 @@ conv3x3_direct_f32(const ConvArgs p)
       if (more)
         store_stage(lds + ((st + 1) & 1) * STAGE);
 #endif
-      __syncthreads();
+      if (!(DK_ABL & 8))
+        __syncthreads();
     }
   };
 
@@ -280,6 +314,19 @@ conv3x3_direct_f32(const ConvArgs p)
   else
     run(std::integral_constant<int, PPT>{});
 
+  if (DK_ABL & 1)
+  {
+    float sacc = 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+    if (sacc == 123.456f)
+      p.y[tid] = sacc;
+    return;
+  }
   conv_epilogue<BM, BN, WM, WN, TM, TN>(p, acc, m0, n0, 0, wm, wn, l31, lh);
 }
 
@@ -358,7 +405,7 @@ const char* dk_conv_direct_config_name(int dcfg)
 
 const char* dk_conv_direct_kernel_name(int dcfg, int pc)
 {
-  static char buf[128];
+  static thread_local char buf[128];
   if (dcfg < 0 || dcfg >= g_ndcfg || pc < 0 || pc > 3)
     return nullptr;
   const DirectCfg& c = g_dcfgs[dcfg];
@@ -388,12 +435,7 @@ int dk_conv_direct_launch(ConvArgs a, int dcfg, hipStream_t st)
   a.tiles_m = (a.M + c.bm - 1) / c.bm;
   a.tiles_n = (a.N + c.bn - 1) / c.bn;
   const int bytes = lds_bytes(c, pc);
-  static bool attr_set[16][4];
-  if (!attr_set[dcfg][pc])
-  {
-    CHECK_HIP(hipFuncSetAttribute((const void*)c.kernel[pc], hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    attr_set[dcfg][pc] = true;
-  }
+  dk_set_max_dynamic_lds((const void*)c.kernel[pc], bytes);
   a.groups = 1;
   conv_args_finish(a);
   const long long nblk = conv_pick_partition(a, (size_t)a.M * a.K * sizeof(float), c.bm);

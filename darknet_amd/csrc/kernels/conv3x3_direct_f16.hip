@@ -366,12 +366,7 @@ int dk_conv_forward_half_direct(const DkConvDesc* d, const float* x, const void*
     conv_args_finish(a);
     const long long nblk = conv_pick_partition(a, (size_t)M * C * 9 * 2, c.bm);
     const int lds_bytes = 2 * (c.bm * A_PITCH + 2 * g_hpc[pc].rows * g_hpc[pc].p * 16);
-    static bool attr_set[1][4];
-    if (!attr_set[ci][pc])
-    {
-      CHECK_HIP(hipFuncSetAttribute((const void*)c.kernel[pc], hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-      attr_set[ci][pc] = true;
-    }
+    dk_set_max_dynamic_lds((const void*)c.kernel[pc], lds_bytes);
     hipLaunchKernelGGL(c.kernel[pc], dim3((unsigned)nblk), dim3((c.bm / c.wm) * (c.bn / c.wn) * 64),
         lds_bytes, st, a);
     CHECK_HIP(hipPeekAtLastError());

@@ -45,6 +45,7 @@ struct ConvArgs
   float* y2;
   unsigned y2_bytes;
   int Mtot2, m_split;
+  int nwork;         // persistent kernels: number of virtual workgroups (the grid a one-tile-per-block launch would use)
 };
 
 // exact floor(n / d) for 0 <= n < 2^31, d > 0, given inv = 1.0 / d: the double estimate is within
@@ -194,6 +195,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
   // generic per-element path: edge tiles, exact mish / logistic / relu, pre-activation store
   auto emit_generic = [&](auto check) {
     constexpr bool CHECK = decltype(check)::value;
+    // (no `continue` inside the unrolled loops: with early exits the optimizer gives up on the
+    // full unroll of the larger tiles, acc is then indexed dynamically and the whole accumulator
+    // array -- the K loop's too -- ends up in scratch memory)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
     {
@@ -201,17 +205,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
       for (int r = 0; r < 16; ++r)
       {
         const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (CHECK && m >= p.M)
-          continue;
-        const float bv = p.bias ? p.bias[g * p.M + m] : 0.f;
+        const bool mok = !CHECK || m < p.M;
+        const float bv = (p.bias && mok) ? p.bias[g * p.M + m] : 0.f;
         const unsigned mo = (unsigned)(m - msub) * row_bytes;
 #pragma unroll
         for (int j = 0; j < TN; ++j)
         {
-          if (CHECK && obase[j] == 0xFFFFFFFFu)
-            continue;
+          const bool ok = mok && !(CHECK && obase[j] == 0xFFFFFFFFu);
           float v = acc[i][j][r] + bv;
-          const unsigned o = obase[j] + mo;
+          // masked elements are sent beyond the end of the buffers: the range check drops them
+          const unsigned o = ok ? obase[j] + mo : 0xFFFFFFF0u;
           if (has_ain)
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ar, (int)o, 0, 0);
           v = dk_activate(v, act);

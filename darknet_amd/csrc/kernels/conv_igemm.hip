@@ -48,6 +48,20 @@
 #include "conv_common.h"
 
 
+// Diagnostic builds (make EXTRA=-DDK_ABL=<bits> LIB=... OUT=...; never the shipped library): remove one
+// part of the kernel to price it (cdna_hip_programming.md section 7, "Ablate").  Results are wrong by
+// construction.  bit 0: no epilogue, 1: no LDS staging writes, 2: no global loads, 3: no barriers,
+// 4: no LDS fragment reads.
+#ifndef DK_ABL
+#define DK_ABL 0
+#endif
+#define DK_BARRIER()      \
+  do                      \
+  {                       \
+    if (!(DK_ABL & 8))    \
+      __syncthreads();    \
+  } while (0)
+
 // AVEC: weights rows are read as float4 (needs K % 4 == 0).
 // BVEC: 1x1 / stride 1 / pad 0 / OHW % 4 == 0: the B tile is a plain strided
 //       matrix, read as float4 along n and written to LDS with ds_write_b128.
@@ -210,6 +224,14 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
   auto load_tile = [&](int k0, auto sc) {
     float(&ra)[NA] = ra2[decltype(sc)::value];
     float(&rb)[NB] = rb2[decltype(sc)::value];
+    if (DK_ABL & 4)
+    {
+#pragma unroll
+      for (int j = 0; j < NA; ++j) ra[j] = (float)(k0 + j);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) rb[j] = (float)(k0 - j);
+      return;
+    }
     // ---- A (weights [M][K] row-major)
     if (AVEC)
     {
@@ -259,6 +281,14 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
   auto store_tile = [&](float* st, auto sc) {
     float(&ra)[NA] = ra2[decltype(sc)::value];
     float(&rb)[NB] = rb2[decltype(sc)::value];
+    if (DK_ABL & 2)
+    {
+#pragma unroll
+      for (int j = 0; j < NA; ++j) asm volatile("" ::"v"(ra[j]));
+#pragma unroll
+      for (int j = 0; j < NB; ++j) asm volatile("" ::"v"(rb[j]));
+      return;
+    }
     float* As = st;
     float* Bs = st + A_FLOATS;
     if (AVEC)
@@ -319,10 +349,20 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
     for (int s = 0; s < BK / 2; ++s)
     {
       float a[TM], b[TN];
+      if (DK_ABL & 16)
+      {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = (float)(lane + i + s);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = (float)(lane - j - s);
+      }
+      else
+      {
 #pragma unroll
       for (int i = 0; i < TM; ++i) a[i] = As[i * 32 * AS + 2 * s];
 #pragma unroll
       for (int j = 0; j < TN; ++j) b[j] = Bs[(2 * s) * BN + j * 32];
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -335,7 +375,7 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
   {
     load_tile(0, I0{});
     store_tile(lds, I0{});
-    __syncthreads();
+    DK_BARRIER();
     for (int kt = 0; kt < nkt; ++kt)
     {
       const bool more = (kt + 1) < nkt;
@@ -344,7 +384,7 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
       compute(lds + (kt & 1) * STAGE);
       if (more)
         store_tile(lds + ((kt + 1) & 1) * STAGE, I0{});
-      __syncthreads();
+      DK_BARRIER();
     }
   }
   else
@@ -354,7 +394,7 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
     if (nkt > 1)
       load_tile(BK, I1{});
     store_tile(lds, I0{});
-    __syncthreads();
+    DK_BARRIER();
     for (int kt = 0; kt < nkt; kt += 2)
     {
       if (kt + 2 < nkt)
@@ -362,7 +402,7 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
       compute(lds);
       if (kt + 1 < nkt)
         store_tile(lds + STAGE, I1{});
-      __syncthreads();
+      DK_BARRIER();
       if (kt + 1 >= nkt)
         break;
       if (kt + 3 < nkt)
@@ -370,10 +410,24 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
       compute(lds + STAGE);
       if (kt + 2 < nkt)
         store_tile(lds, I0{});
-      __syncthreads();
+      DK_BARRIER();
     }
   }
 
+  if (DK_ABL & 1)
+  {
+    // keep the accumulators alive without the epilogue
+    float sacc = 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+    if (sacc == 123.456f)
+      p.y[tid] = sacc;
+    return;
+  }
   conv_epilogue<BM, BN, WM, WN, TM, TN>(p, acc, m0, n0, g, wm, wn, l31, lh);
 }
 
@@ -387,6 +441,13 @@ const char* dk_conv_direct_config_name(int dcfg);
 const char* dk_conv_direct_kernel_name(int dcfg, int pitch_class);
 bool dk_conv_direct_applicable(const DkConvDesc* d, const float* weights, int dcfg);
 int dk_conv_direct_launch(ConvArgs a, int dcfg, hipStream_t st);
+// conv1x1_dma.hip: LDS-DMA ring GEMM for 1x1/s1 layers; numbered after the direct configurations.
+int dk_conv_dma1x1_num_configs();
+const char* dk_conv_dma1x1_config_name(int c);
+const char* dk_conv_dma1x1_kernel_name(int c);
+int dk_conv_dma1x1_bm(int c);
+bool dk_conv_dma1x1_applicable(const DkConvDesc* d, const float* x, const float* weights, int c);
+void dk_conv_dma1x1_launch(ConvArgs a, int c, hipStream_t st);
 
 namespace
 {
@@ -579,14 +640,21 @@ Plan& get_plan(const DkConvDesc* d, int K, int C, int mode = 0)
 }
 }  // namespace
 
+// configuration index space: [0, g_ncfg) gather shapes, then the direct 3x3 shapes, then the
+// LDS-DMA 1x1 shapes
+static int dma_base() { return g_ncfg + dk_conv_direct_num_configs(); }
+static int total_cfgs() { return dma_base() + dk_conv_dma1x1_num_configs(); }
+
 extern "C" int dk_conv_force_config(int cfg)
 {
   g_forced = cfg;
-  return g_ncfg + dk_conv_direct_num_configs();
+  return total_cfgs();
 }
 
 extern "C" const char* dk_conv_config_name(int cfg)
 {
+  if (cfg >= dma_base())
+    return dk_conv_dma1x1_config_name(cfg - dma_base());
   if (cfg >= g_ncfg)
     return dk_conv_direct_config_name(cfg - g_ncfg);
   return (cfg >= 0 && cfg < g_ncfg) ? g_cfgs[cfg].name : nullptr;
@@ -598,6 +666,8 @@ bool dk_conv_config_applicable(const DkConvDesc* d, int cfg)
     return false;
   if (cfg < g_ncfg)
     return true;
+  if (cfg >= dma_base())
+    return dk_conv_dma1x1_applicable(d, nullptr, nullptr, cfg - dma_base());
   return dk_conv_direct_applicable(d, nullptr, cfg - g_ncfg);
 }
 
@@ -649,14 +719,16 @@ extern "C" int dk_profile_read(double* out, int max_cfgs)
     (void)hipEventDestroy(r.e1);
   }
   g_prof.clear();
-  return (g_ncfg + dk_conv_direct_num_configs()) * 4;
+  return total_cfgs() * 4;
 }
 
 // Kernel symbol exactly as rocprofv3 prints it, for profile slot idx = cfg*4 + AVEC + 2*BVEC
 // (direct 3x3 configurations: cfg*4 + pitch class).
 extern "C" __attribute__((visibility("default"))) const char* dk_conv_kernel_name(int idx)
 {
-  static char buf[128];
+  static thread_local char buf[128];
+  if (idx >= dma_base() * 4)
+    return dk_conv_dma1x1_kernel_name(idx / 4 - dma_base());
   if (idx >= g_ncfg * 4)
     return dk_conv_direct_kernel_name(idx / 4 - g_ncfg, idx & 3);
   if (idx < 0)
@@ -687,7 +759,7 @@ extern "C" __attribute__((visibility("default"))) void DkTestBlockTile(int tiles
   out[0] = (int)nblk; out[1] = a.pm; out[2] = ok; out[3] = g; out[4] = tm; out[5] = tn;
 }
 
-int dk_conv_num_configs() { return g_ncfg + dk_conv_direct_num_configs(); }
+int dk_conv_num_configs() { return total_cfgs(); }
 
 const int2* dk_conv_ktab(const DkConvDesc* d, int K, int C, int mode) { return get_plan(d, K, C, mode).ktab; }
 
@@ -786,6 +858,7 @@ int dk_conv_forward_cfg(const DkConvDesc* d, const float* x, const float* weight
   {
     const int nb = (d->batch - b0 < chunk) ? d->batch - b0 : chunk;
     ConvArgs a;
+    memset(&a, 0, sizeof(a));
     a.x = x + (size_t)b0 * in_img;
     a.w = weights;
     a.bias = biases;
@@ -809,10 +882,40 @@ int dk_conv_forward_cfg(const DkConvDesc* d, const float* x, const float* weight
     a.act = d->activation;
     if (d->activation == DK_MISH && fast_mish())
       a.act |= DK_ACT_FAST;
+    {
+      // timing-only diagnostics (cdna_hip_programming.md section 7: zero-record descriptors drop the
+      // loads / stores of ONE buffer while the instruction stream stays): DK_DEBUG_DROP bit 0 = input
+      // loads, bit 1 = output stores, bit 2 = weight loads.  Results are garbage by construction.
+      static const int drop = getenv("DK_DEBUG_DROP") ? atoi(getenv("DK_DEBUG_DROP")) : 0;
+      if (drop & 1) a.x_bytes = 0;
+      if (drop & 2) a.y_bytes = a.y2_bytes = 0;
+      if (drop & 4) a.w_bytes = 0;
+    }
     int want = cfg_override >= 0 ? cfg_override : (g_forced >= 0 ? g_forced : env_cfg());
-    const int ntot = g_ncfg + dk_conv_direct_num_configs();
+    const int ntot = dma_base();
     if (want < 0)
       want = pick_direct(d, weights, M, a.N);
+    if (want >= dma_base() && want < total_cfgs() && dk_conv_dma1x1_applicable(d, a.x, weights, want - dma_base()) &&
+        !(dual && dual->m_split % dk_conv_dma1x1_bm(want - dma_base())))
+    {
+      ProfRec pr;
+      if (g_prof_on)
+      {
+        CHECK_HIP(hipEventCreate(&pr.e0));
+        CHECK_HIP(hipEventCreate(&pr.e1));
+        CHECK_HIP(hipEventRecord(pr.e0, st));
+      }
+      dk_conv_dma1x1_launch(a, want - dma_base(), st);
+      CHECK_HIP(hipPeekAtLastError());
+      if (g_prof_on)
+      {
+        CHECK_HIP(hipEventRecord(pr.e1, st));
+        pr.cfg = want * 4;
+        pr.gflop = 2.0 * (double)M * K * (double)a.N / 1e9;
+        g_prof.push_back(pr);
+      }
+      continue;
+    }
     if (want >= g_ncfg && want < ntot && dk_conv_direct_applicable(d, weights, want - g_ncfg))
     {
       ProfRec pr;

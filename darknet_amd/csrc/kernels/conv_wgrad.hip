@@ -22,6 +22,7 @@
 
 #include "dark_hip.h"
 #include "dk_kernels.h"
+#include "dk_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -342,12 +343,7 @@ extern "C" int dk_conv_backward_weights(const DkConvDesc* d, const float* x, con
     const long long nblk = tiles * a.nsplit;
     const bool avec = (a.OHW % 4 == 0) && (((uintptr_t)a.delta & 15) == 0);
     const int lds_bytes = 2 * (BM + BKO) * LS * (int)sizeof(float);
-    static bool attr_set[4][2];
-    if (!attr_set[ci][avec])
-    {
-      CHECK_HIP(hipFuncSetAttribute((const void*)c.kernel[avec], hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-      attr_set[ci][avec] = true;
-    }
+    dk_set_max_dynamic_lds((const void*)c.kernel[avec], lds_bytes);
     hipLaunchKernelGGL(c.kernel[avec], dim3((unsigned)nblk), dim3(T), lds_bytes, st, a);
     CHECK_HIP(hipPeekAtLastError());
   }

@@ -39,3 +39,7 @@ bool dk_fast_mish_enabled();
 // conv3x3_direct_f16.hip: fp16-operand patch-in-LDS kernel with weights pre-packed per layer
 int dk_conv_forward_half_direct(const DkConvDesc* d, const float* x, const void* packed_weights,
     const float* biases, float* y, const float* residual, void* stream, int out_ctot);
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel, size): function
+// attributes are per device, and several host threads (one per GPU) may launch concurrently
+void dk_set_max_dynamic_lds(const void* kernel, int bytes);

@@ -204,6 +204,22 @@ DK_API int dk_upsample_backward(const float* delta, int w, int h, int c, int bat
 DK_API int dk_sgd_update(float* weights, float* weight_updates, size_t n, int batch,
     float learning_rate, float momentum, float decay, int use_decay, void* stream);
 
+/* ---- sibling-cfg layer kinds ----------------------------------- */
+/* ForwardAvgpoolLayerGpu / BackwardAvgpoolLayerGpu, src/avgpool_layer_kernels.cu:9-62
+ * (CPU: src/avgpool_layer.cpp:40-72): out[b][k] = mean over the h*w plane; backward ADDS
+ * delta[b][k] / (h*w) to every input pixel. */
+DK_API int dk_avgpool_forward(const float* in, float* out, int batch, int c, int h, int w, void* stream);
+DK_API int dk_avgpool_backward(const float* delta, float* prev_delta, int batch, int c, int h, int w, void* stream);
+/* scale_channels_gpu / backward_scale_channels_gpu (src/scale_channels_layer.c:70-160):
+ * out = act(scale * from) with one scale per (image, channel) (scale_wh = 0, in: [batch][c])
+ * or per (image, pixel) (scale_wh = 1, in: [batch][h*w]); backward: delta already holds
+ * d/d(out) * act'; from_delta += scale * delta, in_delta += sum(delta * from).  Either
+ * gradient target may be NULL. */
+DK_API int dk_scale_channels_forward(const float* in, const float* from, float* out, int batch, int out_c,
+    int out_h, int out_w, int scale_wh, int activation, void* stream);
+DK_API int dk_scale_channels_backward(const float* delta, const float* in, const float* from, float* from_delta,
+    float* in_delta, int batch, int out_c, int out_h, int out_w, int scale_wh, void* stream);
+
 /* Profiling hooks used by bench.py (measurement only): when enabled every
  * dk_conv_forward is bracketed by HIP events on its stream; dk_profile_read
  * synchronises and returns per tile-configuration totals.

@@ -96,6 +96,23 @@ typedef struct MostProbDet
   float prob;
 } MostProbDet;
 
+/* ---- training data (src/yolo_core.h:561-576) ----------------------------- */
+typedef struct matrix
+{
+  int rows, cols;
+  float** vals;
+} matrix;
+
+typedef struct data
+{
+  int w, h;
+  matrix X;
+  matrix y;
+  int shallow;
+  int* num_boxes;
+  Box** boxes;
+} data;
+
 /* ---- layer / network (field names: src/yolo_core.h:149-558) ------------- */
 struct layer;
 typedef struct layer layer;
@@ -148,6 +165,8 @@ struct layer
   int reverse;
   float scale;
   float bflops;
+  int scale_wh;          /* [scale_channels]: 1 = one scale per pixel instead of per channel */
+  float probability;     /* [dropout] */
 
   /* yolo */
   int classes, total;
@@ -206,6 +225,7 @@ struct layer
   struct layer* dual_peer; /* the other conv of a dual launch (master <-> slave), or NULL */
   void* weights_half_gpu; /* fp16 weights packed for conv3x3_direct_f16 (inference plan with cudnn_half), or NULL */
   int delta_in_arena;    /* delta_gpu points into net->delta_arena_gpu (not freed per layer) */
+  int buffers_aliased;   /* [dropout]: output_gpu / delta_gpu are the previous layer's (not freed here) */
   float* out_view;       /* producer: where the output really goes (a channel slice), or NULL */
   int out_view_ctot;     /* producer: channels of the tensor out_view is a slice of */
   float* out_alias;      /* route with one input: the source's buffer, or NULL */
@@ -271,6 +291,11 @@ struct Network
   size_t delta_arena_size;
   float* grad_bucket;    /* caller-owned contiguous gradient bucket (DkAttachGradBucket), or NULL */
   int grad_replicas;     /* data-parallel replicas whose buckets are summed before the update (DkSetReplicas) */
+  void* dp;              /* data-parallel state of this replica (TrainNetworks: bucket, RCCL communicator, streams) */
+  void* fwd_done_ev;     /* NetworkPredictDevice: forward finished (hipEvent_t) */
+  void* copy_done_ev;    /* NetworkPredictDevice: head copies of the previous call finished */
+  int copy_pending;
+  int opt_graph, opt_pull_heads; /* per-network overrides of DkSetGraph / DkSetPullHeads (0/1), -1... stored +1: 0 = follow the process-wide setting */
   int planned;           /* DkPlanInference ran (fusion plan, packed/dual weight copies exist) */
   int backward_stopped;  /* train: a stopbackward layer ended this step's backward sweep (DkBackwardRange segments) */
 };
@@ -309,6 +334,9 @@ LIB_API Detection* GetNetworkBoxes(Network* net, float thresh, int* num);
 LIB_API Detection* MakeNetworkBoxes(Network* net, float thresh, int* num);
 LIB_API void FreeDetections(Detection* dets, int n);
 LIB_API void FuseConvBatchNorm(Network* net);
+/* src/network.cpp:255-410: new input resolution; every layer re-derives its geometry and
+ * re-allocates its tensors, plans / tap tables / the captured graph are rebuilt */
+LIB_API void ResizeNetwork(Network* net, int w, int h);
 LIB_API void ForwardNetworkGpu(Network* net, NetworkState state);
 LIB_API float* NetworkPredictGpu(Network* net, float* input);
 LIB_API float* GetNetworkOutputGpu(Network* net);
@@ -332,6 +360,30 @@ LIB_API void BackwardRouteLayerGpu(layer* l, NetworkState state);
 LIB_API void BackwardShortcutLayerGpu(layer* l, NetworkState state);
 LIB_API void BackwardUpsampleLayerGpu(layer* l, NetworkState state);
 LIB_API void BackwardYoloLayerGpu(layer* l, NetworkState state);
+/* multi-GPU data parallelism in C (src/network.cpp:210-239, src/network_kernels.cu:398-484): one host
+ * thread + stream + RCCL communicator per GPU; the replicas' gradient buckets are all-reduced (sum)
+ * every iteration, overlapped with the backward pass, instead of the reference's weight averaging
+ * every `sync_interval` iterations (accepted, unused).  `nets` is an array of `num_gpus` Network
+ * structs, each parsed with train = true after cuda_set_device(its GPU); d holds
+ * batch x subdivisions x num_gpus rows. */
+LIB_API float TrainNetwork(Network* net, data d);
+LIB_API float TrainNetworks(Network* nets, int num_gpus, data d, int sync_interval);
+LIB_API void SyncNetworks(Network* nets, int num_gpus);
+LIB_API void get_next_batch(data d, int n, int offset, float* X, float* y);
+LIB_API data GetPartialData(data d, int idx, int num_split);
+/* flat helpers for FFI callers */
+LIB_API Network* DkNetworkArrayCreate(int n);
+LIB_API Network* DkNetworkArrayAt(Network* nets, int i);
+LIB_API void DkNetworkArrayDestroy(Network* nets, int n);
+LIB_API float DkTrainNetworksFlat(Network* nets, int num_gpus, float* X, int x_cols, float* y, int y_cols,
+    int rows, int sync_interval);
+/* backward-order slices of the gradient bucket used by the overlapped all-reduce:
+ * out[4i..4i+3] = hi, lo, offset, count; returns the number of slices */
+LIB_API int DkBucketSegments(Network* net, int nseg, long long* out, int max_segs);
+/* per-network overrides of the process-wide DkSetGraph / DkSetPullHeads (thread-safe use:
+ * one thread per network); value < 0 returns to the process-wide setting */
+LIB_API void DkNetSetGraph(Network* net, int on);
+LIB_API void DkNetSetPullHeads(Network* net, int on);
 /* additive: drive the backward pass from a given yolo-layer delta (host array of
  * batch*outputs floats, kept by reference) instead of the yolo loss */
 LIB_API void DkSetYoloDelta(Network* net, int layer_index, float* host_delta);
@@ -373,6 +425,29 @@ LIB_API void ForwardConvolutionalLayerGpu(layer* l, NetworkState state);
 LIB_API void PushConvolutionalLayer(layer* l);
 LIB_API void PullConvolutionalLayer(layer* l);
 LIB_API void add_bias_gpu(float* output, float* biases, int batch, int n, int size);
+LIB_API void backward_bias_gpu(float* bias_updates, float* delta, int batch, int n, int size);
+/* upstream-darknet spellings of the same slots */
+LIB_API void forward_convolutional_layer_gpu(layer* l, NetworkState state);
+LIB_API void backward_convolutional_layer_gpu(layer* l, NetworkState state);
+LIB_API void update_convolutional_layer_gpu(layer* l, int batch, float learning_rate, float momentum,
+    float decay, float loss_scale);
+LIB_API void init_cpu(void);
+/* sibling-cfg layer kinds: src/batchnorm_layer.cpp:9-88, :268-425; src/avgpool_layer.cpp:6-72;
+ * src/scale_channels_layer.c:9-160 */
+LIB_API void FillBatchnormLayer(layer* l, int batch, int w, int h, int c, int train);
+LIB_API void ForwardBatchnormLayerGpu(layer* l, NetworkState state);
+LIB_API void BackwardBatchnormLayerGpu(layer* l, NetworkState state);
+LIB_API void UpdateBatchnormLayerGpu(layer* l, int batch, float learning_rate, float momentum, float decay,
+    float loss_scale);
+LIB_API void PushBatchnormLayer(layer* l);
+LIB_API void PullBatchnormLayer(layer* l);
+LIB_API void FillAvgpoolLayer(layer* l, int batch, int w, int h, int c);
+LIB_API void ForwardAvgpoolLayerGpu(layer* l, NetworkState state);
+LIB_API void BackwardAvgpoolLayerGpu(layer* l, NetworkState state);
+LIB_API void FillScaleChannelsLayer(layer* l, int batch, int index, int w, int h, int c, int w2, int h2,
+    int c2, int scale_wh);
+LIB_API void ForwardScaleChannelsLayerGpu(layer* l, NetworkState state);
+LIB_API void BackwardScaleChannelsLayerGpu(layer* l, NetworkState state);
 LIB_API void ForwardMaxpoolLayerGpu(layer* l, NetworkState state);
 LIB_API void ForwardRouteLayerGpu(layer* l, NetworkState state);
 LIB_API void ForwardShortcutLayerGpu(layer* l, NetworkState state);

@@ -35,8 +35,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # enum values, src/yolo_core.h:69-92 and :112-138
 LOGISTIC, RELU, LINEAR, LEAKY, MISH = 0, 1, 4, 8, 17
 ACT_NAMES = {"logistic": LOGISTIC, "relu": RELU, "linear": LINEAR,
-             "leaky": LEAKY, "mish": MISH}
+             "leaky": LEAKY, "mish": MISH, "relu6": 2, "relie": 3, "ramp": 5, "tanh": 6, "plse": 7,
+             "elu": 9, "loggy": 10, "stair": 11, "hardtan": 12, "lhtan": 13, "selu": 14, "gelu": 15,
+             "swish": 16}
 CONVOLUTIONAL, MAXPOOL, ROUTE, SHORTCUT, YOLO, UPSAMPLE = 0, 2, 7, 11, 17, 21
+DROPOUT, AVGPOOL, SCALE_CHANNELS, BATCHNORM = 5, 9, 12, 14
 
 _lib = None
 
@@ -232,6 +235,33 @@ def parse_cfg(path, batch=1, train=False):
             l.out_c = l.n * (l.classes + 4 + 1)
             assert l.out_c == c, "filters= before [yolo] does not match classes/mask"
             l.bflops = 0
+        elif name == "[batchnorm]":
+            # FillBatchnormLayer, src/batchnorm_layer.cpp:9-88
+            l.type = BATCHNORM
+            l.n = c
+            l.out_w, l.out_h, l.out_c = w, h, c
+            l.bflops = 0
+        elif name in ("[avgpool]", "[avg]"):
+            # FillAvgpoolLayer, src/avgpool_layer.cpp:6-40
+            l.type = AVGPOOL
+            l.out_w, l.out_h, l.out_c = 1, 1, c
+            l.bflops = 0
+        elif name == "[scale_channels]":
+            # ParseScaleChannels / FillScaleChannelsLayer, src/parser.cpp:781-802, src/scale_channels_layer.c:9-48
+            l.type = SCALE_CHANNELS
+            frm = int(o["from"])
+            l.from_index = frm if frm >= 0 else idx + frm
+            l.scale_wh = _int(o, "scale_wh", 0)
+            src = net.layers[l.from_index]
+            l.out_w, l.out_h, l.out_c = src.out_w, src.out_h, src.out_c
+            l.activation = ACT_NAMES[o.get("activation", "linear")]
+            l.bflops = 0
+        elif name == "[dropout]":
+            # inference: identity on the previous layer's buffers (src/parser.cpp:1232-1242)
+            l.type = DROPOUT
+            l.probability = _float(o, "probability", .2)
+            l.out_w, l.out_h, l.out_c = w, h, c
+            l.bflops = 0
         else:
             raise ValueError("oracle: unsupported section %s" % name)
         l.outputs = l.out_h * l.out_w * l.out_c
@@ -262,6 +292,10 @@ def load_weights(net, path):
         return a
 
     for l in net.layers:
+        if l.type == BATCHNORM:   # LoadBatchnormWeights, src/parser.cpp:1683-1693
+            l.biases, l.scales = take(l.c), take(l.c)
+            l.rolling_mean, l.rolling_variance = take(l.c), take(l.c)
+            continue
         if l.type != CONVOLUTIONAL:
             continue
         l.biases = take(l.n)
@@ -278,6 +312,8 @@ def weights_file_size(net):
     for l in net.layers:
         if l.type == CONVOLUTIONAL:
             n += 4 * (l.n + l.nweights + (3 * l.n if l.batch_normalize else 0))
+        if l.type == BATCHNORM:
+            n += 16 * l.c
     return n
 
 
@@ -352,9 +388,46 @@ def forward(net, x, keep=None, upto=None, half=False):
         elif l.type == YOLO:
             L.orc_yolo_forward(fptr(inp), fptr(out), B, l.w, l.h, l.n, l.classes,
                                F(l.scale_x_y))
+        else:
+            out = _forward_extra(L, net, l, inp, out, train=False)
         l.output = out
         inp = out
     return inp
+
+
+def _bn_defaults(l):
+    for name, v in (("biases", 0), ("scales", 1), ("rolling_mean", 0), ("rolling_variance", 0)):
+        if not hasattr(l, name):
+            setattr(l, name, np.full(l.c, v, np.float32))
+    for name in ("mean", "variance", "mean_delta", "variance_delta"):
+        if not hasattr(l, name):
+            setattr(l, name, np.zeros(l.c, np.float32))
+
+
+def _forward_extra(L, net, l, inp, out, train):
+    """[batchnorm] / [avgpool] / [scale_channels] / [dropout] forward (src/batchnorm_layer.cpp:206-238,
+    src/avgpool_layer.cpp:40-56, src/scale_channels_layer.c:70-95)."""
+    B = l.batch
+    if l.type == BATCHNORM:
+        _bn_defaults(l)
+        out[...] = inp
+        l.x = np.zeros_like(out)
+        l.x_norm = np.zeros_like(out)
+        L.orc_batchnorm_forward(fptr(out), B, l.c, l.out_h * l.out_w, fptr(l.scales), fptr(l.biases),
+                                fptr(l.rolling_mean), fptr(l.rolling_variance), fptr(l.mean),
+                                fptr(l.variance), fptr(l.x), fptr(l.x_norm), 1 if train else 0)
+    elif l.type == AVGPOOL:
+        L.orc_avgpool_forward(fptr(inp), fptr(out), B, l.c, l.h, l.w)
+    elif l.type == SCALE_CHANNELS:
+        L.orc_scale_channels_forward(fptr(inp), fptr(net.layers[l.from_index].output), fptr(out), B,
+                                     l.out_c, l.out_h, l.out_w, l.scale_wh)
+        L.orc_activate_array(fptr(out), out.size, l.activation)
+    elif l.type == DROPOUT:
+        assert not train, "oracle: [dropout] in train mode needs the reference's RNG stream"
+        out = inp
+    else:
+        raise ValueError("oracle: unsupported layer type %d" % l.type)
+    return out
 
 
 def get_boxes(net, thresh, b=0):
@@ -397,6 +470,10 @@ def load_network_train(cfg, weights, batch):
                 l.scale_updates = np.zeros(l.n, np.float32)
                 for name in ("mean", "variance", "mean_delta", "variance_delta"):
                     setattr(l, name, np.zeros(l.n, np.float32))
+        if l.type == BATCHNORM:
+            _bn_defaults(l)
+            l.bias_updates = np.zeros(l.c, np.float32)
+            l.scale_updates = np.zeros(l.c, np.float32)
     return net
 
 
@@ -448,6 +525,8 @@ def forward_train(net, x):
             L.orc_upsample_forward(fptr(inp), l.w, l.h, l.c, B, l.stride, F(l.scale), fptr(out))
         elif l.type == YOLO:
             L.orc_yolo_forward(fptr(inp), fptr(out), B, l.w, l.h, l.n, l.classes, F(l.scale_x_y))
+        else:
+            out = _forward_extra(L, net, l, inp, out, train=True)
         l.output = out
         inp = out
     return inp
@@ -494,6 +573,20 @@ def backward(net):
             L.orc_maxpool_backward(fptr(l.delta), iptr(l.indexes), tot, fptr(p_delta))
         elif l.type == UPSAMPLE:
             L.orc_upsample_backward(fptr(l.delta), l.w, l.h, l.c, B, l.stride, F(l.scale), fptr(p_delta))
+        elif l.type == BATCHNORM:
+            # BackwardBatchnormLayer, src/batchnorm_layer.cpp:240-255 (bias_updates stay untouched on the CPU)
+            L.orc_batchnorm_backward(fptr(l.delta), B, l.c, l.out_h * l.out_w, fptr(l.scales), fptr(l.x), fptr(l.x_norm),
+                                     fptr(l.mean), fptr(l.variance), fptr(l.mean_delta),
+                                     fptr(l.variance_delta), fptr(l.scale_updates))
+            if p_delta is not None:
+                p_delta[...] = l.delta
+        elif l.type == AVGPOOL:
+            L.orc_avgpool_backward(fptr(l.delta), fptr(p_delta), B, l.c, l.h, l.w)
+        elif l.type == SCALE_CHANNELS:
+            L.orc_gradient_array(fptr(l.output), tot, l.activation, fptr(l.delta))
+            frm = net.layers[l.from_index]
+            L.orc_scale_channels_backward(fptr(l.delta), fptr(p_in), fptr(frm.output), fptr(frm.delta), fptr(p_delta),
+                                          B, l.out_c, l.out_h, l.out_w, l.scale_wh)
 
 
 def update(net, actual_batch, lr, momentum, decay):
@@ -505,3 +598,6 @@ def update(net, actual_batch, lr, momentum, decay):
                               fptr(l.bias_updates), fptr(l.scales) if l.batch_normalize else None,
                               fptr(l.scale_updates) if l.batch_normalize else None, l.n, actual_batch,
                               F(lr), F(momentum), F(decay))
+        elif l.type == BATCHNORM:
+            L.orc_batchnorm_update(fptr(l.biases), fptr(l.bias_updates), fptr(l.scales), fptr(l.scale_updates),
+                                   l.c, actual_batch, F(lr), F(momentum))

@@ -927,3 +927,79 @@ int orc_yolo_detections(const float* output, int b, int lw, int lh,
     }
   return count;
 }
+
+/* ---- sibling-cfg layer kinds -------------------------------------- */
+
+/* ForwardAvgpoolLayer, src/avgpool_layer.cpp:40-56: sequential fp32 sum / (h*w). */
+void orc_avgpool_forward(const float* in, float* out, int batch, int c, int h, int w)
+{
+  for (int b = 0; b < batch; ++b)
+    for (int k = 0; k < c; ++k)
+    {
+      const int out_index = k + b * c;
+      out[out_index] = 0;
+      for (int i = 0; i < h * w; ++i)
+      {
+        const size_t in_index = (size_t)i + (size_t)h * w * (k + b * c);
+        out[out_index] += in[in_index];
+      }
+      out[out_index] /= h * w;
+    }
+}
+
+/* BackwardAvgpoolLayer, src/avgpool_layer.cpp:58-72 */
+void orc_avgpool_backward(const float* delta, float* prev_delta, int batch, int c, int h, int w)
+{
+  for (int b = 0; b < batch; ++b)
+    for (int k = 0; k < c; ++k)
+    {
+      const int out_index = k + b * c;
+      for (int i = 0; i < h * w; ++i)
+      {
+        const size_t in_index = (size_t)i + (size_t)h * w * (k + b * c);
+        prev_delta[in_index] += delta[out_index] / (h * w);
+      }
+    }
+}
+
+/* ForwardScaleChannelsLayer, src/scale_channels_layer.c:70-95 (activation by the caller) */
+void orc_scale_channels_forward(const float* in, const float* from, float* out, int batch,
+    int out_c, int out_h, int out_w, int scale_wh)
+{
+  const int size = batch * out_c * out_w * out_h;
+  const int channel_size = out_w * out_h;
+  const int batch_size = out_c * out_w * out_h;
+  if (scale_wh)
+    for (int i = 0; i < size; ++i)
+    {
+      const int input_index = i % channel_size + (i / batch_size) * channel_size;
+      out[i] = in[input_index] * from[i];
+    }
+  else
+    for (int i = 0; i < size; ++i) out[i] = in[i / channel_size] * from[i];
+}
+
+/* BackwardScaleChannelsLayer, src/scale_channels_layer.c:97-127 (gradient_array by the caller) */
+void orc_scale_channels_backward(const float* delta, const float* in, const float* from,
+    float* from_delta, float* in_delta, int batch, int out_c, int out_h, int out_w, int scale_wh)
+{
+  const int size = batch * out_c * out_w * out_h;
+  const int channel_size = out_w * out_h;
+  const int batch_size = out_c * out_w * out_h;
+  for (int i = 0; i < size; ++i)
+  {
+    const int si = scale_wh ? (i % channel_size + (i / batch_size) * channel_size) : i / channel_size;
+    in_delta[si] += delta[i] * from[i];
+    from_delta[i] += in[si] * delta[i];
+  }
+}
+
+/* UpdateBatchnormLayer, src/batchnorm_layer.cpp:257-266 */
+void orc_batchnorm_update(float* biases, float* bias_updates, float* scales, float* scale_updates,
+    int c, int batch, float learning_rate, float momentum)
+{
+  for (int i = 0; i < c; ++i) biases[i] += (learning_rate / batch) * bias_updates[i];
+  for (int i = 0; i < c; ++i) bias_updates[i] *= momentum;
+  for (int i = 0; i < c; ++i) scales[i] += (learning_rate / batch) * scale_updates[i];
+  for (int i = 0; i < c; ++i) scale_updates[i] *= momentum;
+}

@@ -3,6 +3,7 @@ HIP path vs (a) the CPU oracle on the same seeded inputs, (b) the golden
 fixtures dumped from the real reference, (c) size-independent properties at the
 BASELINE.json sizes.  fp32 activations within util.REL (1e-4, util.py); detection
 box indices / class ids bit-exact at a guard-banded threshold."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -239,3 +240,39 @@ def test_properties_at_baseline_size(gpu, weights):
     net2.close()
     L.DkSetFusion(1)
     L.DkSetGraph(1)
+
+
+def test_resize_network_vs_oracle(gpu, tmp_path):
+    """ResizeNetwork (src/network.cpp:255-410): yolov4-tiny loaded at 416x416 (batch 2, planned
+    inference net with fusion / zero-copy / graph), resized to 320x352, must equal the oracle parsed
+    at that resolution; then back to 416x416 (re-plan, graph re-captured)."""
+    name = "yolov4-tiny"
+    L = gpu.lib()
+    L.ResizeNetwork.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    w = str(tmp_path / "w.weights")
+    netutil.synth_weights_for(gpu, name, w)
+    net = netutil.DkNet(gpu, netutil.cfg_path(name), w, batch=2)
+    x0 = synth.make_input(2, 3, 416, 416)
+    net.predict(x0)
+    net.predict(x0)   # graph replay
+    heads0 = {i: net.output(i).copy() for i in range(net.n) if net.info(i)["type"] == O.YOLO}
+    for (nw, nh) in ((320, 352), (416, 416)):
+        L.ResizeNetwork(net.p, nw, nh)
+        a = (C.c_int * 8)()
+        L.DkNetworkInfo(net.p, a)
+        assert (a[2], a[3]) == (nw, nh)
+        cfg = str(tmp_path / ("r%d.cfg" % nw))
+        open(cfg, "w").write(open(netutil.cfg_path(name)).read().replace("width=416", "width=%d" % nw).replace("height=416", "height=%d" % nh))
+        onet = O.load_network(cfg, w, batch=2)
+        x = synth.make_input(2, 3, nh, nw, seed=5)
+        O.forward(onet, x)
+        net.inputs = 3 * nw * nh
+        for rep in range(2):   # eager, then the re-captured graph
+            net.predict(x)
+            for i, l in enumerate(onet.layers):
+                if l.type == O.YOLO:
+                    util.assert_close(net.output(i), l.output, "resized %dx%d head %d (run %d)" % (nw, nh, i, rep))
+    net.predict(x0)
+    for i, h0 in heads0.items():
+        assert np.array_equal(net.output(i), h0), "416x416 after resizing there and back differs"
+    net.close()

@@ -255,3 +255,50 @@ def test_activations_grid(gpu):
     # flip the rounding of (1+e^x), i.e. move softplus by 2^-23 and mish by up to
     # |x| * 1.2e-7 ~ 2e-6 absolute.  Bar: 1e-4 relative + 2.5e-6 absolute.
     assert np.all(np.abs(got - ref) <= 1e-4 * np.abs(ref) + 2.5e-6)
+
+
+DMA1X1_CASES = [
+    # batch, c, h, w, n, act : 1x1 / stride 1 layers the LDS-DMA ring kernel takes (c % 32 == 0, h*w % 4 == 0)
+    (2, 64, 16, 16, 64, "MISH"),      # N = 512: full tiles
+    (3, 32, 12, 12, 255, "LINEAR"),   # one K stage, ragged M (head), ragged N (432)
+    (2, 128, 38, 38, 256, "LEAKY"),   # 1444-pixel images: tiles straddle images
+    (1, 96, 20, 20, 40, "MISH"),      # three K stages, M < one tile
+    (2, 256, 8, 8, 128, "LEAKY"),     # eight K stages: the ring wraps
+    (1, 64, 152, 152, 32, "MISH"),    # M = 32
+]
+
+
+@pytest.mark.parametrize("case", DMA1X1_CASES)
+def test_conv_dma1x1_vs_oracle(gpu, case):
+    """LDS-DMA ring GEMM (conv1x1_dma.hip), every compiled shape: vs the CPU oracle, with a residual
+    (straight-line epilogue), and BITWISE equal to the gather kernel (same k order, same MFMA chain)."""
+    batch, c, h, w, n, actname = case
+    act = getattr(O, actname)
+    rng = np.random.default_rng(hash(case) & 0xFFFF)
+    x = rng.uniform(-1, 1, (batch, c, h, w)).astype(np.float32)
+    wt = (rng.uniform(-1, 1, (n, c, 1, 1)) * np.sqrt(2.0 / c)).astype(np.float32)
+    bias = rng.uniform(-.5, .5, n).astype(np.float32)
+    res = rng.uniform(-1, 1, (batch, n, h, w)).astype(np.float32)
+    ref, _ = orc_conv(x, wt, bias, batch, c, h, w, n, 1, 1, 0, act)
+    L = gpu.lib()
+    ncfg = L.dk_conv_force_config(-1)
+    names = [L.dk_conv_config_name(i).decode() for i in range(ncfg)]
+    dma = [i for i, nm in enumerate(names) if nm.startswith("dma1x1")]
+    assert dma
+    L.dk_conv_force_config(3)   # gather 64x64x16
+    y_gather = gpu.conv_forward(x, wt, bias, batch, c, h, w, n, 1, 1, 0, act)
+    L.dk_profile_enable(1)
+    for cfg in dma:
+        L.dk_conv_force_config(cfg)
+        y = gpu.conv_forward(x, wt, bias, batch, c, h, w, n, 1, 1, 0, act)
+        util.assert_close(y, ref, "conv %s %s" % (names[cfg], case))
+        assert np.array_equal(y, y_gather), "dma1x1 %s differs bitwise from the gather kernel" % names[cfg]
+        y = gpu.conv_forward(x, wt, bias, batch, c, h, w, n, 1, 1, 0, act, residual=res)
+        util.assert_close(y, ref + res, "conv + residual %s %s" % (names[cfg], case))
+    # the DMA kernel really ran (no silent fallback to the gather)
+    out = (C.c_double * (3 * 256))()
+    L.dk_profile_read(out, 256)
+    L.dk_profile_enable(0)
+    for cfg in dma:
+        assert out[cfg * 4 * 3] == 2, "config %s did not launch" % names[cfg]
+    L.dk_conv_force_config(-1)

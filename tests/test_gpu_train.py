@@ -451,3 +451,63 @@ def test_split_train_step_equals_train_network_datum(gpu, tmp_path):
             # float atomics in the weight gradient make two runs agree only to rounding
             util.assert_close(gb, ga, "layer %d gradient %d" % (i, which), rel=1e-4, atol_rms=1e-5)
     a.close(); b.close()
+
+
+def test_train_networks_c_entry_equals_subdivisions(gpu, tmp_path):
+    """The C-level data-parallel entry (TrainNetworks, csrc/host/multigpu.cpp; reference signature
+    network_kernels.cu:446-484): two replicas in one Network array, one host thread each, gradient
+    buckets summed every iteration.  On a one-GPU box both replicas sit on device 0, so the collective
+    is the library's local-sum path (RCCL needs distinct devices); everything else -- threads, bucket
+    attachment, B = batch x subdivisions x replicas, momentum carry-over -- is the multi-GPU code.
+    Must equal ONE replica run with subdivisions = 2 over two iterations."""
+    g, cfg, wpath, x = train_fixture(tmp_path)
+    L = gpu.lib()
+    for fn, at, rt in (("DkNetworkArrayCreate", [C.c_int], VP), ("DkNetworkArrayAt", [VP, C.c_int], VP),
+                       ("DkNetworkArrayDestroy", [VP, C.c_int], None),
+                       ("LoadNetwork", [VP, C.c_char_p, C.c_char_p, C.c_bool, C.c_bool], C.c_bool),
+                       ("DkTrainNetworksFlat", [VP, C.c_int, VP, C.c_int, VP, C.c_int, C.c_int, C.c_int], C.c_float),
+                       ("DkSetMaxIter", [VP, C.c_int], None), ("DkSetSubdivisions", [VP, C.c_int], None),
+                       ("TrainNetworkDatum", [VP, VP, VP], C.c_float), ("UpdateNetworkGpu", [VP], None),
+                       ("DkAdvanceIteration", [VP], None), ("SyncNetworks", [VP, C.c_int], None),
+                       ("DkLayerPull", [VP, C.c_int, C.c_int, VP, C.c_size_t], C.c_long)):
+        getattr(L, fn).argtypes = at
+        getattr(L, fn).restype = rt
+    B = int(g["batch"])
+    assert B == 2
+    one = str(tmp_path / "one.cfg")
+    open(one, "w").write(open(cfg).read().replace("batch=%d" % B, "batch=1"))
+    sub = str(tmp_path / "sub.cfg")
+    open(sub, "w").write(open(cfg).read().replace("subdivisions=1", "subdivisions=%d" % B))
+    truth = np.ascontiguousarray(g["truth"])
+    X = np.ascontiguousarray(x.reshape(B, -1))
+    T = np.ascontiguousarray(truth.reshape(B, -1))
+    STEPS = 2
+    ref = netutil.DkNet(gpu, sub, wpath, train=True)
+    L.DkSetMaxIter(ref.p, 1000)
+    for _ in range(STEPS):
+        for i in range(B):
+            L.TrainNetworkDatum(ref.p, X[i:i + 1].ctypes.data, T[i:i + 1].ctypes.data)
+        L.DkAdvanceIteration(ref.p)
+        L.UpdateNetworkGpu(ref.p)
+    nets = L.DkNetworkArrayCreate(B)
+    for i in range(B):
+        p = L.DkNetworkArrayAt(nets, i)
+        assert L.LoadNetwork(p, one.encode(), wpath.encode(), True, False)
+        L.DkSetMaxIter(p, 1000)
+    costs = [L.DkTrainNetworksFlat(nets, B, X.ctypes.data, X.shape[1], T.ctypes.data, T.shape[1], B, 4) for _ in range(STEPS)]
+    assert all(np.isfinite(c) and c > 0 for c in costs)
+    L.SyncNetworks(nets, B)   # averages the (identical) weights and the per-replica rolling statistics
+
+    def weights(p, i, n):
+        out = np.empty(n, np.float32)
+        assert L.DkLayerPull(p, i, 1, out.ctypes.data, n) == n
+        return out
+    p0, p1 = L.DkNetworkArrayAt(nets, 0), L.DkNetworkArrayAt(nets, 1)
+    for i in range(ref.n):
+        f = ref.info(i)
+        if f["type"] == O.CONVOLUTIONAL:
+            a, b0, b1 = weights(ref.p, i, f["nweights"]), weights(p0, i, f["nweights"]), weights(p1, i, f["nweights"])
+            assert np.array_equal(b0, b1), "replicas diverged"
+            util.assert_close(b0, a, "weights after %d TrainNetworks steps, layer %d" % (STEPS, i), rel=2e-5, atol_rms=2e-6)
+    L.DkNetworkArrayDestroy(nets, B)
+    ref.close()

@@ -210,3 +210,31 @@ def test_adam_cfg_is_refused_loudly(dk, tmp_path):
             "L.ParseNetworkCfg(L.DkNetworkCreate(), %r.encode(), True)" % (ROOT, str(cfg)))
     r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode != 0 and b"adam=1 is not supported" in r.stderr
+
+
+def test_c_bucket_segments_equal_python_rule(dk):
+    """The C trainer (TrainNetworks, csrc/host/multigpu.cpp) cuts the gradient bucket into backward-order
+    slices with the same rule as darknet_amd/train_dist.py: bucket_segments."""
+    from darknet_amd.train_dist import bucket_segments
+    L = dk.lib()
+    L.ParseNetworkCfg.restype = C.c_bool
+    L.ParseNetworkCfg.argtypes = [C.c_void_p, C.c_char_p, C.c_bool]
+    L.DkGradBucketOffset.restype = C.c_size_t
+    L.DkGradBucketOffset.argtypes = [C.c_void_p, C.c_int]
+    L.DkBucketSegments.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_longlong), C.c_int]
+    for name in ("yolov4-tiny", "yolov4"):
+        p = L.DkNetworkCreate()
+        assert L.ParseNetworkCfg(p, netutil.cfg_path(name).encode(), True)
+        a = (C.c_int * 8)()
+        L.DkNetworkInfo(p, a)
+        n = a[0]
+        offs = [L.DkGradBucketOffset(p, i) for i in range(n + 1)]
+        convs = [i for i in range(n) if offs[i + 1] > offs[i]]
+        assert convs and offs[-1] > 0
+        for nseg in (1, 2, 4, 7):
+            want = bucket_segments(convs, [offs[i + 1] - offs[i] for i in convs], n, nseg)
+            out = (C.c_longlong * (4 * 16))()
+            k = L.DkBucketSegments(p, nseg, out, 16)
+            got = [tuple(out[4 * i:4 * i + 4]) for i in range(k)]
+            assert got == [tuple(int(v) for v in s) for s in want], (name, nseg)
+        L.DkNetworkDestroy(p)

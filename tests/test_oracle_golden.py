@@ -176,3 +176,44 @@ def test_train_step_golden(tmp_path):
     O.update(net, net.batch * net.subdiv, float(g["lr"]), net.momentum, net.decay)
     for row in g["updated_weight_summaries"]:
         assert np.array_equal(summ(net.layers[int(row[0])].weights), row[1:])
+
+
+def test_extra_layer_kinds_golden(tmp_path):
+    """[batchnorm] / [avgpool] / [scale_channels] / [dropout]: the oracle reproduces,
+    bit for bit, the REAL reference's outputs of every layer of cfg/se-test.cfg (inference) and one
+    train step (forward with batch statistics, backward, update) of the same net without [dropout]
+    and [batchnorm] (tools/make_golden.py extra; see synth.se_cfgs for why those two are left out)."""
+    g = np.load(os.path.join(GOLD, "extra_se-test.npz"))
+    inf, tr = synth.se_cfgs(tmp_path)
+    onet = O.parse_cfg(inf)
+    w = str(tmp_path / "w.weights")
+    synth.write_weights_layers(w, synth.weight_layers_of(onet), seed=2024)
+    onet = O.load_network(inf, w, batch=1)
+    O.forward(onet, synth.make_input(1, onet.c, onet.h, onet.w, seed=12345))
+    kinds = set()
+    for i, l in enumerate(onet.layers):
+        assert np.array_equal(l.output.ravel(), g["inf_out_%d" % i]), i
+        kinds.add(l.type)
+    assert {O.BATCHNORM, O.AVGPOOL, O.SCALE_CHANNELS, O.DROPOUT} <= kinds
+    tnet = O.parse_cfg(tr)
+    tw = str(tmp_path / "tw.weights")
+    synth.write_weights_layers(tw, synth.weight_layers_of(tnet), seed=2024)
+    tnet = O.load_network_train(tr, tw, None)
+    x = synth.make_input(tnet.batch, tnet.c, tnet.h, tnet.w, seed=int(g["train_x_seed"]))
+    O.forward_train(tnet, x)
+    for i, l in enumerate(tnet.layers):
+        assert np.array_equal(l.output.ravel(), g["train_out_%d" % i]), i
+        if l.type == O.YOLO:
+            l.delta[...] = g["train_yolo_delta_%d" % i].reshape(l.delta.shape)
+    O.backward(tnet)
+    checked = 0
+    for i, l in enumerate(tnet.layers):
+        for nm in ("weight_updates", "bias_updates", "scale_updates"):
+            k = "train_%s_%d" % (nm, i)
+            if k in g.files:
+                assert np.array_equal(getattr(l, nm), g[k]), k
+                checked += 1
+        k = "train_delta_%d" % i
+        if k in g.files:
+            assert np.array_equal(l.delta.ravel(), g[k]), k
+    assert checked >= 8

@@ -37,6 +37,10 @@ def main():
             continue
         outputs.append(f["outputs"])
         key = (f["c"], f["h"], f["w"], f["n"], f["size"], f["stride_x"], f["pad"], f["activation"], f["groups"])
+        flt = os.environ.get("DK_SWEEP_FILTER", "")   # e.g. "k1" (1x1 layers), "s2" (stride 2), "k3s1"
+        tag = "k%ds%d" % (f["size"], f["stride_x"])
+        if flt and flt not in tag:
+            continue
         shapes.setdefault(key, []).append(i)
     L.DkNetworkDestroy(p)
     ncfg = L.dk_conv_force_config(-1)
@@ -63,8 +67,8 @@ def main():
             L.dk_profile_enable(1)
             for _ in range(iters):
                 L.dk_conv_forward(C.byref(d), dx.ptr, wt.ptr, bs.ptr, dy.ptr, None, None, None)
-            out = (C.c_double * (3 * 128))()
-            L.dk_profile_read(out, 128)
+            out = (C.c_double * (3 * 256))()
+            L.dk_profile_read(out, 256)
             L.dk_profile_enable(0)
             ms = sum(out[(cfgi * 4 + v) * 3 + 2] for v in range(4)) / iters
             g1 = sum(out[(cfgi * 4 + v) * 3 + 1] for v in range(4)) / iters

@@ -254,6 +254,7 @@ def main():
     gen_net("yolov4-csp", full_heads=False)
     gen_train()
     gen_yololoss()
+    gen_extra()
 
 
 def gen_train(name="yolov4-tiny", B=2):
@@ -364,8 +365,95 @@ def gen_yololoss():
     print("yololoss.npz")
 
 
+se_cfgs = synth.se_cfgs
+
+
+def gen_extra():
+    """Sibling-cfg layer kinds ([batchnorm], [avgpool], [scale_channels], [dropout]) through the REAL
+    reference: every layer's inference output (b=1), and one train step (forward with batch
+    statistics, backward, update) of the cfg without [dropout]; the oracle is asserted bit-identical
+    to the reference on all of it while the fixture is written -> extra_se-test.npz."""
+    inf, tr = se_cfgs()
+    out = {}
+    onet = O.parse_cfg(inf)
+    wpath = "/tmp/_dk_se.weights"
+    synth.write_weights_layers(wpath, synth.weight_layers_of(onet), seed=2024)
+    assert os.path.getsize(wpath) == O.weights_file_size(onet)
+    # ---- inference, batch 1 (the reference forces it)
+    x = synth.make_input(1, onet.c, onet.h, onet.w, seed=12345)
+    rn = reflib.RefNet(inf, wpath)
+    assert rn.n == onet.n == 10
+    rn.predict(x)
+    onet = O.load_network(inf, wpath, batch=1)
+    O.forward(onet, x)
+    for i, l in enumerate(onet.layers):
+        inff = rn.info(i)
+        assert (inff["type"], inff["outputs"], inff["out_c"], inff["out_h"], inff["out_w"]) == \
+            (l.type, l.outputs, l.out_c, l.out_h, l.out_w), (i, inff)
+        r = rn.output(i)
+        assert np.array_equal(r, l.output.ravel()), f"extra inference: oracle != reference at layer {i}"
+        out[f"inf_out_{i}"] = r
+    rn.close()
+    # ---- one train step, batch 2, no dropout
+    B = 2
+    tnet = O.parse_cfg(tr)
+    x2 = synth.make_input(B, tnet.c, tnet.h, tnet.w, seed=777)
+    truth = np.zeros((B, 90 * 5), np.float32)
+    for b in range(B):
+        for t, box in enumerate([(.3, .4, .2, .3, 1), (.6, .5, .4, .35, 0), (.8, .2, .1, .15, 1)]):
+            truth[b, t * 5:(t + 1) * 5] = box
+    twpath = "/tmp/_dk_se_train.weights"
+    synth.write_weights_layers(twpath, synth.weight_layers_of(tnet), seed=2024)
+    wpath = twpath
+    rn = reflib.RefNet(tr, wpath, train=True)
+    assert rn.batch == B
+    rn.L.ref_set_max_iter(rn.p, 1000)
+    cost = rn.L.ref_train_datum(rn.p, fp(x2), fp(truth))
+    out["train_x_seed"], out["train_truth"], out["train_cost"] = np.int32(777), truth, np.float32(cost)
+    onet = O.load_network_train(tr, wpath, None)
+    O.forward_train(onet, x2)
+    for i, l in enumerate(onet.layers):
+        assert np.array_equal(rn.output(i), l.output.ravel()), f"extra train forward: oracle != reference at {i}"
+        out[f"train_out_{i}"] = l.output.ravel().copy()
+        if l.type == O.YOLO:
+            d = rn.arr(i, 6, l.batch * l.outputs)
+            out[f"train_yolo_delta_{i}"] = d.copy()
+            l.delta[...] = d.reshape(l.delta.shape)
+    O.backward(onet)
+    for i, l in enumerate(onet.layers):
+        for which, nm, n in ((7, "weight_updates", getattr(l, "nweights", 0)), (8, "bias_updates", getattr(l, "n", 0)),
+                             (9, "scale_updates", getattr(l, "n", 0))):
+            o = getattr(l, nm, None)
+            r = rn.arr(i, which, n) if (o is not None and n) else None
+            if r is None or o is None:
+                continue
+            assert np.array_equal(r, o), f"extra train backward: oracle != reference at {i} {nm}"
+            out[f"train_{nm}_{i}"] = r
+        if l.type != O.YOLO and l.type != O.DROPOUT:
+            r = rn.arr(i, 6, l.batch * l.outputs)
+            assert np.array_equal(r, l.delta.ravel()), f"extra train delta: oracle != reference at {i}"
+            out[f"train_delta_{i}"] = r
+    rn.L.ref_update(rn.p)
+    lr = float(rn.L.ref_curr_lr(rn.p))
+    out["train_lr"] = np.float32(lr)
+    O.update(onet, onet.batch * onet.subdiv, lr, onet.momentum, onet.decay)
+    for i, l in enumerate(onet.layers):
+        if l.type == O.CONVOLUTIONAL:
+            assert np.array_equal(rn.arr(i, 1, l.nweights), l.weights), f"extra update: weights at {i}"
+            assert np.array_equal(rn.arr(i, 2, l.n), l.biases)
+        if l.type == O.BATCHNORM:
+            assert np.array_equal(rn.arr(i, 2, l.c), l.biases), f"extra update: bn biases at {i}"
+            assert np.array_equal(rn.arr(i, 3, l.c), l.scales), f"extra update: bn scales at {i}"
+            out[f"train_bn_scales_{i}"] = l.scales.copy()
+    rn.close()
+    np.savez_compressed(os.path.join(GOLD, "extra_se-test.npz"), **out)
+    print("extra_se-test.npz: cost %.5f lr %.3e, %d arrays" % (cost, lr, len(out)))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "train":
+    if len(sys.argv) > 1 and sys.argv[1] == "extra":
+        gen_extra()
+    elif len(sys.argv) > 1 and sys.argv[1] == "train":
         gen_train()
     elif len(sys.argv) > 1 and sys.argv[1] == "yololoss":
         gen_yololoss()

@@ -8,7 +8,9 @@ i=0
 for grp in "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVES" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS" \
            "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES" \
-           "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU"; do
+           "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU" \
+           "SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM"; do
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $R/$OUT/g$i -- python3 $R/tools/conv_one.py "$@" 6 > $R/$OUT/g$i.log 2>&1 || exit 1
 done
+python3 $R/tools/pmc_one_summary.py $R/$OUT

@@ -87,3 +87,60 @@ def write_weights(path, convs, seed=2024, head_bias=None):
             sc = np.float32(np.sqrt(2.0 / fan))
             nw = n * cpg * size * size
             (sc * (np.float32(2) * g.uniform(nw) - np.float32(1))).astype(np.float32).tofile(f)
+
+
+def write_weights_layers(path, layers, seed=2024):
+    """Like write_weights for nets that also hold standalone [batchnorm] layers.  layers: in file
+    order, ("conv", n, c_per_group, size, batch_normalize) or ("batchnorm", c): biases, scales,
+    rolling_mean, rolling_variance with the conv BN distributions (src/parser.cpp:1683-1693)."""
+    g = LCG(seed)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<iiiQ", 0, 2, 5, 0))
+        for ent in layers:
+            if ent[0] == "batchnorm":
+                c = ent[1]
+                (np.float32(0.1) * (g.uniform(c) - np.float32(.5))).astype(np.float32).tofile(f)
+                (np.float32(.75) + np.float32(.5) * g.uniform(c)).astype(np.float32).tofile(f)
+                (np.float32(0.1) * (g.uniform(c) - np.float32(.5))).astype(np.float32).tofile(f)
+                (np.float32(.5) + g.uniform(c)).astype(np.float32).tofile(f)
+                continue
+            _, n, cpg, size, bn = ent
+            (np.float32(0.1) * (g.uniform(n) - np.float32(.5))).astype(np.float32).tofile(f)
+            if bn:
+                (np.float32(.75) + np.float32(.5) * g.uniform(n)).astype(np.float32).tofile(f)
+                (np.float32(0.1) * (g.uniform(n) - np.float32(.5))).astype(np.float32).tofile(f)
+                (np.float32(.5) + g.uniform(n)).astype(np.float32).tofile(f)
+            sc = np.float32(np.sqrt(2.0 / (size * size * cpg)))
+            (sc * (np.float32(2) * g.uniform(n * cpg * size * size) - np.float32(1))).astype(np.float32).tofile(f)
+
+
+def weight_layers_of(onet):
+    """The (oracle-parsed) network's weight-bearing layers in .weights order."""
+    out = []
+    for l in onet.layers:
+        if l.type == 0:       # CONVOLUTIONAL
+            out.append(("conv", l.n, l.c // l.groups, l.size, l.batch_normalize))
+        elif l.type == 14:    # BATCHNORM
+            out.append(("batchnorm", l.c))
+    return out
+
+
+def se_cfgs(outdir="/tmp"):
+    """cfg/se-test.cfg as is (inference) and, for the train step, without the [dropout] section (the
+    reference's dropout draws from rand(), which no fixture can pin) and without the standalone
+    [batchnorm] (the reference's CPU path cannot train it: FillBatchnormLayer allocates l->x /
+    l->x_norm only under GPU, src/batchnorm_layer.cpp:9-88, and ForwardBatchnormLayer :224-227
+    writes them -> it crashes; train-mode standalone [batchnorm] is therefore pinned through the
+    conv-BN path's identical kernels, not directly).  Returns (inference cfg, train cfg) paths."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    txt = open(os.path.join(root, "cfg", "se-test.cfg")).read()
+    inf, tr = os.path.join(str(outdir), "_dk_se_inf.cfg"), os.path.join(str(outdir), "_dk_se_train.cfg")
+    open(inf, "w").write(txt)
+    t = txt
+    for sec in ("[dropout]", "[batchnorm]"):
+        a = t.index("\n" + sec + "\n") + 1
+        b = t.index("[convolutional]", a)
+        t = t[:a] + t[b:]
+    open(tr, "w").write(t)
+    return inf, tr
