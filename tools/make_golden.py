@@ -255,6 +255,7 @@ def main():
     gen_train()
     gen_yololoss()
     gen_extra()
+    gen_map()
 
 
 def gen_train(name="yolov4-tiny", B=2):
@@ -450,8 +451,77 @@ def gen_extra():
     print("extra_se-test.npz: cost %.5f lr %.3e, %d arrays" % (cost, lr, len(out)))
 
 
+def gen_map(name="yolov4-tiny", K=4):
+    """Evaluator fixture: the REAL reference's post-NMS detections (NetworkPredict,
+    GetNetworkBoxes, NmsSort through oracle/_ref) on K seeded u8 images, a label set derived from
+    them, and the mAP the oracle's restatement of ValidateDetector's arithmetic gives on those
+    detections -> map_<cfg>.npz.  (detector.cpp itself needs OpenCV and is not in the _ref build.)"""
+    from oracle import orc_map
+    cfg = os.path.join(ROOT, "cfg", name + ".cfg")
+    net = O.parse_cfg(cfg)
+    convs = [(l.n, l.c // l.groups, l.size, l.batch_normalize) for l in net.layers if l.type == O.CONVOLUTIONAL]
+    wpath = f"/tmp/_dk_{name}.weights"
+    synth.write_weights(wpath, convs, seed=2024)
+    rn = reflib.RefNet(cfg, wpath)
+    seeds = [4100 + i for i in range(K)]
+    xs = [synth.u8_to_chw(synth.make_u8_image(net.w, net.h, sd)) for sd in seeds]
+    # class probability (objectness x class score) of every predictor and class over the K images ->
+    # a guard-banded threshold that lets ~250 (predictor, class) pairs per image through.  (With the
+    # synthetic weights every score hovers around 0.5, so the reference's default .005 would pass all
+    # 2535 x 80 pairs; only the sparse upper tail of the distribution has gaps wide enough for a
+    # guard band.)
+    probs = []
+    for x in xs:
+        rn.predict(x.reshape(1, -1))
+        for i in range(rn.n):
+            inf = rn.info(i)
+            if inf["type"] == O.YOLO:
+                o = rn.output(i).reshape(3, 5 + inf["classes"], -1)
+                probs.append((o[:, 4:5, :] * o[:, 5:, :]).ravel())
+    srt = np.sort(np.concatenate(probs))[::-1]
+    lo, hi = 150 * K, 350 * K
+    gaps = srt[lo:hi] - srt[lo + 1:hi + 1]
+    j = lo + int(np.argmax(gaps))
+    thresh = float((srt[j] + srt[j + 1]) / 2)
+    print("threshold gap", gaps.max(), "rank", j)
+    assert gaps.max() > 2e-5, "no guard band around the threshold"
+    last = [l for l in net.layers if l.type == O.YOLO][-1]
+    classes = last.classes
+    nms = 0.45
+    rng = np.random.default_rng(99)
+    dets_all, gts_all = [], []
+    for x in xs:
+        rn.predict(x.reshape(1, -1))
+        d = rn.boxes(thresh)
+        nd = np.ascontiguousarray(d)
+        rn.L.ref_nms_sort(nd.ctypes.data_as(FP), len(nd), classes, nms, last.nms_kind, last.beta_nms)
+        dd = np.concatenate([nd[:, :4], nd[:, 5:]], 1)   # drop objectness: [x, y, w, h, prob...]
+        dd = np.ascontiguousarray(dd[(dd[:, 4:] != 0).any(1)])   # detections without a surviving class add nothing
+        dets_all.append(dd)
+        best = np.argsort(-dd[:, 4:].max(1))[:6]
+        g = []
+        for r, k in enumerate(best):
+            b = dd[k, :4].copy()
+            if r % 3 == 2:
+                b[2:] *= np.float32(0.9)                  # still IoU ~0.8 with the detection
+            g.append([float(np.argmax(dd[k, 4:]))] + list(b))
+        for _ in range(2):                                # labels nothing will match
+            g.append([float(rng.integers(0, classes)), .05 + .02 * rng.uniform(), .9, .03, .04])
+        gts_all.append(np.array(g, np.float32))
+    rn.close()
+    m, aps = orc_map.mean_average_precision(dets_all, gts_all, classes, 0.5)
+    out = {"seeds": np.array(seeds, np.int32), "thresh": np.float32(thresh), "nms": np.float32(nms), "map": np.float64(m),
+           "ap": np.array(aps, np.float64), "n_dets": np.array([len(d) for d in dets_all], np.int32),
+           "dets": np.concatenate(dets_all), "n_gts": np.array([len(g) for g in gts_all], np.int32),
+           "gts": np.concatenate(gts_all)}
+    np.savez_compressed(os.path.join(GOLD, f"map_{name}.npz"), **out)
+    print(f"map_{name}.npz: thresh {thresh:.6f}, dets/image {[len(d) for d in dets_all]}, mAP {m:.6f}")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "extra":
+    if len(sys.argv) > 1 and sys.argv[1] == "map":
+        gen_map()
+    elif len(sys.argv) > 1 and sys.argv[1] == "extra":
         gen_extra()
     elif len(sys.argv) > 1 and sys.argv[1] == "train":
         gen_train()

@@ -144,3 +144,14 @@ def se_cfgs(outdir="/tmp"):
         t = t[:a] + t[b:]
     open(tr, "w").write(t)
     return inf, tr
+
+
+def make_u8_image(w, h, seed):
+    """Interleaved RGB u8 test image [h, w, 3] from the LCG stream (values 0..255)."""
+    v = LCG(seed).uniform(w * h * 3)
+    return (v * np.float32(256.0)).astype(np.uint8).reshape(h, w, 3)
+
+
+def u8_to_chw(img):
+    """Mat2Image (src/visualize.cpp:26-55): chw[k][y][x] = hwc[y][x][k] / 255.0f"""
+    return np.ascontiguousarray(img.transpose(2, 0, 1).astype(np.float32) / np.float32(255.0))
