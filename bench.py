@@ -39,6 +39,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: Peak FP32 (matrix), dense
+FP16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: Peak BF16/FP16 MFMA, dense (not the 2:1-sparse figure)
 CFG = "yolov4"
 BATCH_PER_GPU = 16
 
@@ -111,7 +112,9 @@ def main():
     tmp = tempfile.mkdtemp(prefix="dkbench%d_" % ctx.rank)
     wpath = os.path.join(tmp, args.cfg + ".weights")
     netapi.synth_weights_for(dk, args.cfg, wpath, seed=2024)
+    t_load = time.perf_counter()
     net = netapi.DkNet(dk, netapi.cfg_path(args.cfg), wpath, batch=args.batch)
+    load_seconds = time.perf_counter() - t_load   # parse + weights + BN fold + plan + per-layer tile autotune
     # this rank's shard of the global synthetic batch
     lo, hi = dkdist.shard_range(args.batch * ctx.world, ctx.rank, ctx.world)
     x = synth.make_input(hi, net.c, net.h, net.w)[lo:hi]
@@ -189,10 +192,10 @@ def main():
         prof_steps = 3
         for _ in range(prof_steps):
             step()
-        out = (C.c_double * (3 * 256))()
-        ncfg = L.dk_profile_read(out, 256)
+        out = (C.c_double * (3 * 512))()
+        ncfg = L.dk_profile_read(out, 512)
         L.dk_profile_enable(0)
-        rows = [(out[3 * i + 2], out[3 * i], out[3 * i + 1], i) for i in range(ncfg) if out[3 * i] > 0]
+        rows = [(out[3 * i + 2], out[3 * i], out[3 * i + 1], i) for i in range(min(ncfg, 512)) if out[3 * i] > 0]
         rows.sort(reverse=True)
         ms, launches, gflop, ci = rows[0]
         tot_ms = sum(r[0] for r in rows)
@@ -200,9 +203,11 @@ def main():
         achieved = gflop / ms  # GFLOP / ms = TFLOP/s
         kname = L.dk_conv_kernel_name(ci).decode()
         traffic = pmc_traffic_for(kname)
+        # the dominant kernel's own arithmetic decides its roof: fp16-operand kernels run on the fp16 MFMA pipe
+        peak = FP16_MFMA_PEAK_TFLOPS if "f16" in kname else FP32_MFMA_PEAK_TFLOPS
         roofline = {
-            "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+            "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+            "frac": achieved / peak, "traffic": traffic,
             "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate "
                             "rocprofv3 --pmc passes of this command: tools/pmc_traffic.sh -> profiles/)",
             "kernel": kname,
@@ -210,16 +215,28 @@ def main():
             "gflop_per_launch": gflop / launches, "avg_launch_ms": ms / launches,
             "all_conv_kernels": {"achieved": tot_gf / tot_ms, "frac": tot_gf / tot_ms / FP32_MFMA_PEAK_TFLOPS,
                                  "ms_per_step": tot_ms / prof_steps, "gflop_per_step": tot_gf / prof_steps},
+            "kernels": [{"kernel": L.dk_conv_kernel_name(r[3]).decode(), "ms_per_step": r[0] / prof_steps,
+                         "launches_per_step": r[1] / prof_steps, "tflops": r[2] / r[0]} for r in rows[:8]],
         }
 
     # ---- CPU baseline on the host cores (rank 0, N = 1 only) -----------------
     cpu_baseline = None
     if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
-        try:
+        def cpu_leg(cfg_name, w, seconds, threads=None):
+            env = dict(os.environ)
+            if threads:
+                env["OMP_NUM_THREADS"] = str(threads)
             r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py"),
-                                netapi.cfg_path(args.cfg), wpath, str(args.cpu_seconds)],
-                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
-            cpu_baseline = json.loads(r.stdout.decode().strip().splitlines()[-1])
+                                netapi.cfg_path(cfg_name), w, str(seconds)],
+                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, env=env)
+            return json.loads(r.stdout.decode().strip().splitlines()[-1])
+        try:
+            cpu_baseline = cpu_leg(args.cfg, wpath, args.cpu_seconds)
+            # BASELINE configs[0] (C1): yolov4-tiny 416x416 b=1 on the CPU path, all cores and one thread
+            tw = os.path.join(tmp, "yolov4-tiny.weights")
+            netapi.synth_weights_for(dk, "yolov4-tiny", tw, seed=2024)
+            cpu_baseline["c1_yolov4_tiny_416_b1_all_cores"] = cpu_leg("yolov4-tiny", tw, 4.0)
+            cpu_baseline["c1_yolov4_tiny_416_b1_one_thread"] = cpu_leg("yolov4-tiny", tw, 4.0, threads=1)
         except Exception as e:  # the baseline is reported, never required
             log("cpu_baseline failed:", e)
 
@@ -238,10 +255,12 @@ def main():
                        "parallelism": "batch-sharded replicas x%d, no data-path collective" % ctx.world},
             "frac_of_fp32_mfma_roofline": value * 128.459e9 / (ctx.world * FP32_MFMA_PEAK_TFLOPS * 1e12)
             if args.cfg == "yolov4" else None,
+            "gflop_per_image": {"yolov4": 128.459, "yolov4-tiny": 6.910, "yolov4-csp": 77.003}.get(args.cfg),
             "e2e_images_per_sec": e2e,
             "e2e_u8_frames_to_boxes_images_per_sec": e2e_u8,
             "e2e_u8_note": "u8 HWC frames -> device Mat2Image -> forward -> device candidate compaction -> "
                            "Detection arrays for every image; threshold passes %.0f predictors/image" % (ndet / args.batch),
+            "load_seconds_incl_autotune": load_seconds,
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
         }

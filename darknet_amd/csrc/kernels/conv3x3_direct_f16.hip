@@ -367,9 +367,17 @@ int dk_conv_forward_half_direct(const DkConvDesc* d, const float* x, const void*
     const long long nblk = conv_pick_partition(a, (size_t)M * C * 9 * 2, c.bm);
     const int lds_bytes = 2 * (c.bm * A_PITCH + 2 * g_hpc[pc].rows * g_hpc[pc].p * 16);
     dk_set_max_dynamic_lds((const void*)c.kernel[pc], lds_bytes);
+    DkProfScope prof;
+    dk_prof_begin(prof, st);
     hipLaunchKernelGGL(c.kernel[pc], dim3((unsigned)nblk), dim3((c.bm / c.wm) * (c.bn / c.wn) * 64),
         lds_bytes, st, a);
     CHECK_HIP(hipPeekAtLastError());
+    if (prof.e0)
+    {
+      char nm[96];
+      snprintf(nm, sizeof(nm), "conv3x3_direct_f16<%d, %d, %d, %d, %d, %d>", c.bm, c.bn, c.wm, c.wn, g_hpc[pc].p, g_hpc[pc].rows);
+      dk_prof_end(prof, st, dk_prof_named_slot(nm), 2.0 * (double)M * C * 9 * (double)a.N / 1e9);
+    }
   }
   return 0;
 }

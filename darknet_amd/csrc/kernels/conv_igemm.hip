@@ -37,6 +37,7 @@
 #include <string.h>
 
 #include <map>
+#include <string>
 #include <type_traits>
 #include <mutex>
 #include <vector>
@@ -687,6 +688,46 @@ extern "C" int dk_conv_pick_config(const DkConvDesc* d)
 
 extern "C" __attribute__((visibility("default"))) int dk_profile_is_on() { return g_prof_on; }
 
+namespace
+{
+std::vector<std::string> g_named_slots;   // slot 256 + i
+}
+bool dk_prof_on() { return g_prof_on != 0; }
+
+int dk_prof_named_slot(const char* kernel_name)
+{
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (size_t i = 0; i < g_named_slots.size(); ++i)
+    if (g_named_slots[i] == kernel_name)
+      return 256 + (int)i;
+  g_named_slots.push_back(kernel_name);
+  return 256 + (int)g_named_slots.size() - 1;
+}
+
+void dk_prof_begin(DkProfScope& s, void* stream)
+{
+  if (!g_prof_on)
+    return;
+  hipEvent_t e;
+  CHECK_HIP(hipEventCreate(&e));
+  CHECK_HIP(hipEventRecord(e, (hipStream_t)stream));
+  s.e0 = e;
+}
+
+void dk_prof_end(DkProfScope& s, void* stream, int slot, double gflop)
+{
+  if (!s.e0)
+    return;
+  ProfRec pr;
+  pr.e0 = (hipEvent_t)s.e0;
+  CHECK_HIP(hipEventCreate(&pr.e1));
+  CHECK_HIP(hipEventRecord(pr.e1, (hipStream_t)stream));
+  pr.cfg = slot;
+  pr.gflop = gflop;
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_prof.push_back(pr);
+}
+
 extern "C" void dk_profile_enable(int on)
 {
   g_prof_on = on;
@@ -719,7 +760,8 @@ extern "C" int dk_profile_read(double* out, int max_cfgs)
     (void)hipEventDestroy(r.e1);
   }
   g_prof.clear();
-  return total_cfgs() * 4;
+  const int named = 256 + (int)g_named_slots.size();
+  return named > total_cfgs() * 4 ? named : total_cfgs() * 4;
 }
 
 // Kernel symbol exactly as rocprofv3 prints it, for profile slot idx = cfg*4 + AVEC + 2*BVEC
@@ -727,6 +769,14 @@ extern "C" int dk_profile_read(double* out, int max_cfgs)
 extern "C" __attribute__((visibility("default"))) const char* dk_conv_kernel_name(int idx)
 {
   static thread_local char buf[128];
+  if (idx >= 256)
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (idx - 256 >= (int)g_named_slots.size())
+      return nullptr;
+    snprintf(buf, sizeof(buf), "%s", g_named_slots[idx - 256].c_str());
+    return buf;
+  }
   if (idx >= dma_base() * 4)
     return dk_conv_dma1x1_kernel_name(idx / 4 - dma_base());
   if (idx >= g_ncfg * 4)

@@ -273,11 +273,16 @@ int dk_conv_forward_half_strided(const DkConvDesc* d, const float* x, const floa
     a.tiles_n = (a.N + bn - 1) / bn;
     conv_args_finish(a);
     const long long nblk = conv_pick_partition(a, (size_t)M * K * sizeof(float), bm);
+    DkProfScope prof;
+    dk_prof_begin(prof, st);
     if (small_m)
       hipLaunchKernelGGL((conv_igemm_f16<64, 128, 32, 64>), dim3((unsigned)nblk), dim3(256), 0, st, a);
     else
       hipLaunchKernelGGL((conv_igemm_f16<128, 128, 64, 64>), dim3((unsigned)nblk), dim3(256), 0, st, a);
     CHECK_HIP(hipPeekAtLastError());
+    if (prof.e0)
+      dk_prof_end(prof, st, dk_prof_named_slot(small_m ? "conv_igemm_f16<64, 128, 32, 64>" : "conv_igemm_f16<128, 128, 64, 64>"),
+          2.0 * (double)M * K * (double)a.N / 1e9);
   }
   return 0;
 }

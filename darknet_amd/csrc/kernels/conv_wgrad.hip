@@ -344,8 +344,16 @@ extern "C" int dk_conv_backward_weights(const DkConvDesc* d, const float* x, con
     const bool avec = (a.OHW % 4 == 0) && (((uintptr_t)a.delta & 15) == 0);
     const int lds_bytes = 2 * (BM + BKO) * LS * (int)sizeof(float);
     dk_set_max_dynamic_lds((const void*)c.kernel[avec], lds_bytes);
+    DkProfScope prof;
+    dk_prof_begin(prof, st);
     hipLaunchKernelGGL(c.kernel[avec], dim3((unsigned)nblk), dim3(T), lds_bytes, st, a);
     CHECK_HIP(hipPeekAtLastError());
+    if (prof.e0)
+    {
+      char nm[96];
+      snprintf(nm, sizeof(nm), "conv_wgrad_f32<%d, %d, %s>", c.tm, c.tk, avec ? "true" : "false");
+      dk_prof_end(prof, st, dk_prof_named_slot(nm), 2.0 * (double)M * K * d->groups * (double)a.N / 1e9);
+    }
   }
   return 0;
 }

@@ -81,3 +81,53 @@ __device__ __forceinline__ float dk_activate(float x, int a)
     default: return x;
   }
 }
+
+// gradient(), src/activations.c:351-399 with the scalar definitions of src/activations.h:139-192
+// (as the reference's C++ build evaluates them: int/float promotions, DOUBLE literals in
+// gelu_gradient), evaluated on the layer OUTPUT y; mish (activations.c:426-452) and swish
+// (:413-423) need the saved pre-activation `pre`.
+__device__ __forceinline__ float dk_sech(float x) { return 2 / (expf(x) + expf(-x)); }
+
+__device__ __forceinline__ float dk_act_gradient(float y, float pre, int a)
+{
+  switch (a & 0xff)
+  {
+    case DK_LINEAR: return 1;
+    case DK_LEAKY: return (y > 0) ? 1 : .1f;
+    case DK_LOGISTIC: return (1 - y) * y;
+    case DK_RELU: return (y > 0);
+    case DK_MISH:
+    {
+      const float sp = dk_softplus(pre, 20.f);
+      const float grad_sp = 1 - expf(-sp);
+      const float tsp = tanhf(sp);
+      const float grad_tsp = (1 - tsp * tsp) * grad_sp;
+      return pre * grad_tsp + tsp;
+    }
+    case 16: /* SWISH */ return y + dk_logistic(pre) * (1 - y);
+    case 10: /* LOGGY */
+    {
+      const float h = (y + 1.f) / 2.f;
+      return 2 * (1 - h) * h;
+    }
+    case 2: /* RELU6 */ return (y > 0 && y < 6);
+    case 9: /* ELU */ return (y >= 0) + (y < 0) * (y + 1);
+    case 14: /* SELU */ return (y >= 0) * 1.0507f + (y < 0) * (y + 1.0507f * 1.6732f);
+    case 15: /* GELU */
+    {
+      const float x3 = powf(y, 3.f);
+      return (float)(0.5 * (double)tanhf((float)(0.0356774 * (double)x3 + 0.797885 * (double)y)) +
+                     (0.0535161 * (double)x3 + 0.398942 * (double)y) *
+                         (double)powf(dk_sech((float)(0.0356774 * (double)x3 + 0.797885 * (double)y)), 2.f) +
+                     0.5);
+    }
+    case 3: /* RELIE */ return (y > 0) ? 1 : .01f;
+    case 5: /* RAMP */ return (y > 0) + .1f;
+    case 6: /* TANH */ return 1 - y * y;
+    case 7: /* PLSE */ return (y < 0 || y > 1) ? .01f : .125f;
+    case 11: /* STAIR */ return (floorf(y) == y) ? 0 : 1.0f;
+    case 12: /* HARDTAN */ return (y > -1 && y < 1) ? 1 : 0;
+    case 13: /* LHTAN */ return (y > 0 && y < 1) ? 1 : .001f;
+    default: return 0;
+  }
+}

@@ -43,3 +43,16 @@ int dk_conv_forward_half_direct(const DkConvDesc* d, const float* x, const void*
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel, size): function
 // attributes are per device, and several host threads (one per GPU) may launch concurrently
 void dk_set_max_dynamic_lds(const void* kernel, int bytes);
+
+// ---- launch profiling shared by every conv-family launcher (bench roofline lines) ----------
+// When profiling is on (dk_profile_enable), a launch is bracketed by HIP events on ITS stream and
+// booked under a slot: slots < 256 are the forward conv configurations (cfg * 4 + variant); kernels
+// outside that table (fp16 operands, weight gradient ...) register a slot by their rocprofv3 name.
+struct DkProfScope
+{
+  void* e0 = nullptr;
+};
+bool dk_prof_on();
+int dk_prof_named_slot(const char* kernel_name);
+void dk_prof_begin(DkProfScope& s, void* stream);
+void dk_prof_end(DkProfScope& s, void* stream, int slot, double gflop);

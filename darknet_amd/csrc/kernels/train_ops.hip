@@ -188,26 +188,9 @@ __global__ void gradient_kernel(const float* __restrict__ y, const float* __rest
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
        i += (size_t)gridDim.x * blockDim.x)
   {
-    float g;
-    if (act == DK_MISH)
-    {
-      // gradient_array_mish, activations.c:426-452 (float overloads of exp/tanh)
-      const float inp = act_in[i];
-      const float sp = dk_softplus(inp, 20.f);
-      const float grad_sp = 1 - expf(-sp);
-      const float tsp = tanhf(sp);
-      const float grad_tsp = (1 - tsp * tsp) * grad_sp;
-      g = inp * grad_tsp + tsp;
-    }
-    else if (act == DK_LEAKY)
-      g = (y[i] > 0) ? 1 : .1f;
-    else if (act == DK_LOGISTIC)
-      g = (1 - y[i]) * y[i];
-    else if (act == DK_RELU)
-      g = (y[i] > 0);
-    else
-      g = 1;
-    delta[i] *= g;
+    // gradient_array / gradient_array_mish / gradient_array_swish, activations.c:401-452
+    const float pre = (act == DK_MISH || act == 16) ? act_in[i] : 0.f;
+    delta[i] *= dk_act_gradient(y[i], pre, act);
   }
 }
 
@@ -353,8 +336,10 @@ __device__ __forceinline__ BnRecompute bn_recompute(float x, float delta, float 
   }
   else if (act == DK_RELU)
     g = (a * (a > 0.f) > 0);
-  else
+  else if (act == DK_LINEAR)
     g = 1;
+  else
+    g = dk_act_gradient(dk_activate(a, act), a, act);   // the rarer kinds: recompute the output, then gradient()
   r.d = delta * g;
   return r;
 }
@@ -549,9 +534,9 @@ extern "C" int dk_gradient_array(const float* y, const float* activation_input, 
 {
   if (n == 0 || activation == DK_LINEAR)
     return 0;
-  if (activation == DK_MISH && !activation_input)
+  if ((activation == DK_MISH || activation == 16) && !activation_input)
   {
-    fprintf(stderr, "dk_gradient_array: mish needs the saved pre-activation\n");
+    fprintf(stderr, "dk_gradient_array: mish / swish need the saved pre-activation\n");
     return 1;
   }
   hipLaunchKernelGGL(gradient_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), y,

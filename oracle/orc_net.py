@@ -506,6 +506,10 @@ def forward_train(net, x):
             if l.activation == MISH:
                 l.activation_input = np.zeros_like(out)
                 L.orc_activate_array_mish(fptr(out), out.size, fptr(l.activation_input), fptr(out))
+            elif l.activation == 16:  # SWISH: activate_array_swish keeps sigmoid(x) in activation_input
+                l.activation_input = out.copy()
+                L.orc_activate_array(fptr(l.activation_input), out.size, LOGISTIC)
+                L.orc_activate_array(fptr(out), out.size, l.activation)
             else:
                 L.orc_activate_array(fptr(out), out.size, l.activation)
         elif l.type == MAXPOOL:
@@ -548,6 +552,8 @@ def backward(net):
         elif l.type == CONVOLUTIONAL:
             if l.activation == MISH:
                 L.orc_gradient_array_mish(tot, fptr(l.activation_input), fptr(l.delta))
+            elif l.activation == 16:
+                L.orc_gradient_array_swish(fptr(l.output), tot, fptr(l.activation_input), fptr(l.delta))
             else:
                 L.orc_gradient_array(fptr(l.output), tot, l.activation, fptr(l.delta))
             sp = l.out_h * l.out_w

@@ -361,6 +361,39 @@ void orc_activate_array_mish(
   }
 }
 
+/* the rarer kinds of gradient(), src/activations.c:351-399 with the scalar definitions of
+ * src/activations.h:139-192 as the reference's C++ build evaluates them (int/float promotions,
+ * DOUBLE literals in gelu_gradient); evaluated on the layer OUTPUT like every other kind */
+static float orc_sech(float x) { return 2 / (expf(x) + expf(-x)); }
+static float orc_gradient_rare(float x, int a)
+{
+  switch (a)
+  {
+    case 10: /* LOGGY */
+    {
+      float y = (x + 1.f) / 2.f;
+      return 2 * (1 - y) * y;
+    }
+    case 2: /* RELU6 */ return (x > 0 && x < 6);
+    case 9: /* ELU */ return (x >= 0) + (x < 0) * (x + 1);
+    case 14: /* SELU */ return (x >= 0) * 1.0507f + (x < 0) * (x + 1.0507f * 1.6732f);
+    case 15: /* GELU */
+    {
+      const float x3 = powf(x, 3);
+      return 0.5 * tanhf(0.0356774 * x3 + 0.797885 * x) +
+             (0.0535161 * x3 + 0.398942 * x) * powf(orc_sech(0.0356774 * x3 + 0.797885 * x), 2) + 0.5;
+    }
+    case 3: /* RELIE */ return (x > 0) ? 1 : .01f;
+    case 5: /* RAMP */ return (x > 0) + .1f;
+    case 6: /* TANH */ return 1 - x * x;
+    case 7: /* PLSE */ return (x < 0 || x > 1) ? .01f : .125f;
+    case 11: /* STAIR */ return (floorf(x) == x) ? 0 : 1.0f;
+    case 12: /* HARDTAN */ return (x > -1 && x < 1) ? 1 : 0;
+    case 13: /* LHTAN */ return (x > 0 && x < 1) ? 1 : .001f;
+    default: return 0;
+  }
+}
+
 /* gradient_array, src/activations.c:401-410 with gradient() :351-399:
  * delta *= f'(y) evaluated on the OUTPUT y.  leaky: (y>0)?1:.1f
  * (activations.h:177), logistic: (1-y)*y (:150), linear: 1, relu: (y>0). */
@@ -379,8 +412,18 @@ void orc_gradient_array(const float* y, int n, int a, float* delta)
     else if (a == ORC_RELU)
       g = (y[i] > 0);
     else
-      g = 0;
+      g = orc_gradient_rare(y[i], a);
     delta[i] *= g;
+  }
+}
+
+/* gradient_array_swish, src/activations.c:413-423: x = the swish output, sigmoid = the stored sigmoid */
+void orc_gradient_array_swish(const float* x, int n, const float* sigmoid, float* delta)
+{
+  for (int i = 0; i < n; ++i)
+  {
+    const float swish = x[i];
+    delta[i] *= swish + sigmoid[i] * (1 - swish);
   }
 }
 

@@ -103,3 +103,41 @@ def test_csp_b1_half_vs_rounded_oracle(gpu, tmp_path):
             worst = max(worst, st["max_abs_over_rms"])
     print("yolov4-csp fp16-operand heads: worst max|d|/rms %.3g" % worst)
     net.close()
+
+
+def test_c5_csp_512_b32_half_at_baseline_size(gpu, tmp_path):
+    """BASELINE config C5 at its full size: yolov4-csp 512x512, batch 32, fp16 operands on the 43
+    eligible layers.  Item 17's decoded heads vs the fp16-pre-rounded CPU oracle (the only possible
+    oracle: the reference has no CPU fp16 path -- PARITY UNPINNED by construction for this row), and
+    two size-independent properties at the full batch: items with identical inputs give bitwise
+    identical heads wherever they sit in the batch, and the graph replay reproduces the eager run."""
+    name, B, K = "yolov4-csp", 32, 17
+    wpath = str(tmp_path / "w.weights")
+    netutil.synth_weights_for(gpu, name, wpath)
+    L = gpu.lib()
+    L.DkSetHalf.argtypes = [C.c_int]
+    L.DkSetHalf(1)
+    try:
+        net = netutil.DkNet(gpu, netutil.cfg_path(name), wpath, batch=B)
+    finally:
+        L.DkSetHalf(0)
+    assert (net.w, net.h) == (512, 512)
+    x = synth.make_input(B, net.c, net.h, net.w)
+    x[5] = x[K]
+    x[31] = x[K]
+    net.predict(x)
+    heads = {i: net.output(i).copy() for i in range(net.n) if net.info(i)["type"] == O.YOLO}
+    for i, h in heads.items():
+        assert np.array_equal(h[5], h[K]) and np.array_equal(h[31], h[K]), "head %d depends on the batch position" % i
+    net.predict(x)   # graph replay
+    for i, h in heads.items():
+        assert np.array_equal(net.output(i), h), "head %d: graph replay differs from the eager run" % i
+    onet = O.load_network(netutil.cfg_path(name), wpath, batch=1)
+    O.forward(onet, x[K:K + 1], half=True)
+    worst = 0.0
+    for i, l in enumerate(onet.layers):
+        if l.type == O.YOLO:
+            st = util.assert_close(heads[i][K:K + 1], l.output, "csp b32 half head %d item %d" % (i, K), rel=2e-4, atol_rms=1e-4)
+            worst = max(worst, st["max_abs_over_rms"])
+    print("yolov4-csp 512 b32 fp16 operands: item %d heads worst max|d|/rms %.3g" % (K, worst))
+    net.close()

@@ -257,6 +257,28 @@ def test_activations_grid(gpu):
     assert np.all(np.abs(got - ref) <= 1e-4 * np.abs(ref) + 2.5e-6)
 
 
+def test_rare_activation_gradients_grid(gpu):
+    """dk_gradient_array for the 12 rarer activations and swish vs the reference's own gradient_array
+    values on the grid (tests/golden/ops_grad.npz): exact for the piecewise ones, libm-vs-device ulps
+    for the transcendental ones."""
+    G = gpu.lib()
+    G.dk_gradient_array.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "ops.npz"))
+    gg = np.load(os.path.join(os.path.dirname(__file__), "golden", "ops_grad.npz"))
+    grid = np.ascontiguousarray(gold["act_grid"])
+    for name, act in (("relu6", 2), ("relie", 3), ("ramp", 5), ("tanh", 6), ("plse", 7), ("elu", 9), ("loggy", 10),
+                      ("hardtan", 12), ("lhtan", 13), ("selu", 14), ("gelu", 15), ("relu", 1), ("swish", 16)):
+        y = gpu.DeviceArray(np.ascontiguousarray(gold["act_" + name]))
+        pre = gpu.DeviceArray(grid)
+        d = gpu.DeviceArray(np.ones_like(grid))
+        assert G.dk_gradient_array(y.ptr, pre.ptr, d.ptr, grid.size, act, None) == 0
+        got, ref = d.numpy(), gg["grad_" + name]
+        if name in ("relu6", "relie", "ramp", "plse", "hardtan", "lhtan", "relu", "tanh", "loggy", "elu", "selu"):
+            assert np.array_equal(got, ref), name
+        else:
+            assert np.all(np.abs(got - ref) <= 2e-5 * np.abs(ref) + 1e-6), (name, np.abs(got - ref).max())
+
+
 DMA1X1_CASES = [
     # batch, c, h, w, n, act : 1x1 / stride 1 layers the LDS-DMA ring kernel takes (c % 32 == 0, h*w % 4 == 0)
     (2, 64, 16, 16, 64, "MISH"),      # N = 512: full tiles

@@ -511,3 +511,68 @@ def test_train_networks_c_entry_equals_subdivisions(gpu, tmp_path):
             util.assert_close(b0, a, "weights after %d TrainNetworks steps, layer %d" % (STEPS, i), rel=2e-5, atol_rms=2e-6)
     L.DkNetworkArrayDestroy(nets, B)
     ref.close()
+
+
+def test_c4_yolov4_608_b8_train_step_vs_reference_golden(gpu, tmp_path):
+    """BASELINE config C4 at its per-GPU size: one yolov4 608x608 train step at batch 8 (forward with
+    batch statistics, host yolo loss, backward) against the REAL reference's step on the same inputs
+    (tests/golden/train_yolov4_b8.npz: summaries only -- cost, per layer 64 strided samples + sum of
+    squares of the train-mode output, yolo delta positions, per conv gradient norms).  Integer
+    results (which predictors receive a loss gradient) must match exactly; fp32 activations within
+    the train-mode tolerance of util.py; gradient L2 norms within 1 %."""
+    name, B = "yolov4", 8
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "train_%s_b%d.npz" % (name, B)))
+    cfg = str(tmp_path / "t.cfg")
+    open(cfg, "w").write(open(netutil.cfg_path(name)).read().replace("batch=64", "batch=%d" % B).replace("subdivisions=8", "subdivisions=1"))
+    wpath = str(tmp_path / "w.weights")
+    netutil.synth_weights_for(gpu, name, wpath)
+    L = gpu.lib()
+    L.TrainNetworkDatum.argtypes = [VP, VP, VP]
+    L.TrainNetworkDatum.restype = C.c_float
+    L.DkLayerPull.argtypes = [VP, C.c_int, C.c_int, VP, C.c_size_t]
+    L.DkLayerPull.restype = C.c_long
+    L.DkSetMaxIter.argtypes = [VP, C.c_int]
+    net = netutil.DkNet(gpu, cfg, wpath, train=True)
+    assert net.batch == B and (net.w, net.h) == (608, 608)
+    L.DkSetMaxIter(net.p, 1000)
+    x = np.ascontiguousarray(synth.make_input(B, net.c, net.h, net.w, seed=12345))
+    truth = np.ascontiguousarray(g["truth"])
+    cost = L.TrainNetworkDatum(net.p, x.ctypes.data, truth.ctypes.data)
+    assert abs(cost - float(g["cost"])) <= 2e-3 * float(g["cost"]), (cost, float(g["cost"]))
+
+    def pull(i, which, n):
+        out = np.empty(n, np.float32)
+        assert L.DkLayerPull(net.p, i, which, out.ctypes.data, n) == n
+        return out
+    worst = 0.0
+    for row in g["fwd_summaries"]:
+        i = int(row[0])
+        a = net.output(i).ravel()
+        idx = np.linspace(0, a.size - 1, 64).astype(np.int64)
+        rms = np.sqrt(row[2] / a.size)
+        d = np.abs(a[idx].astype(np.float64) - row[3:])
+        lim = util.REL * np.abs(row[3:]) + util.TRAIN_ATOL_RMS * rms
+        assert np.all(d <= lim), "train forward layer %d: samples off by x%.3g" % (i, float((d / np.maximum(lim, 1e-300)).max()))
+        worst = max(worst, float(d.max() / rms) if rms > 0 else 0.0)
+        ss = float(np.sum(a.astype(np.float64) ** 2))
+        assert abs(ss - row[2]) <= 2e-3 * row[2] + 1e-12, "train forward layer %d: sum of squares %g vs %g" % (i, ss, row[2])
+    print("C4 train forward, 162 layers, samples vs the reference: worst |d|/rms %.3g" % worst)
+    for i in range(net.n):
+        f = net.info(i)
+        if f["type"] == O.YOLO:
+            d = pull(i, 6, f["batch"] * f["outputs"])
+            assert np.array_equal(np.flatnonzero(d), g["yolo_%d_delta_idx" % i]), "yolo %d: different predictors receive a gradient" % i
+            util.assert_close(d[g["yolo_%d_delta_idx" % i]], g["yolo_%d_delta_val" % i], "yolo %d delta" % i, rel=1e-3, atol_rms=1e-3)
+    worst_norm = 0.0
+    for row in g["grad_summaries"]:
+        i, which = int(row[0]), int(row[1])
+        if which not in (7, 9):
+            continue
+        f = net.info(i)
+        n = f["nweights"] if which == 7 else f["n"]
+        a = pull(i, which, n).astype(np.float64)
+        dn = abs(np.sqrt((a * a).sum()) / np.sqrt(row[3]) - 1)
+        worst_norm = max(worst_norm, dn)
+        assert dn < 1e-2, (i, which, dn)
+    print("C4 gradients vs the reference: worst L2-norm deviation %.3g" % worst_norm)
+    net.close()

@@ -57,7 +57,8 @@ def test_every_declared_symbol_is_exported(dk):
 
 @pytest.mark.parametrize("name,layers,bflops,wbytes", [("yolov4-tiny", 38, 6.910, 24251276),
                                                        ("yolov4", 162, 128.459, 257717640),
-                                                       ("yolov4-csp", 175, 77.003, 211944840)])
+                                                       ("yolov4-csp", 175, 77.003, 211944840),
+                                                       ("yolov4x-mish", 201, 139.974, 382983688)])
 def test_parser_invariants(dk, name, layers, bflops, wbytes):
     """The format invariants of SURVEY.md section 4 + layer table == the oracle's."""
     L = dk.lib()

@@ -217,3 +217,23 @@ def test_extra_layer_kinds_golden(tmp_path):
         if k in g.files:
             assert np.array_equal(l.delta.ravel(), g[k]), k
     assert checked >= 8
+
+
+RARE_GRADS = (("relu6", 2), ("relie", 3), ("ramp", 5), ("tanh", 6), ("plse", 7), ("elu", 9), ("loggy", 10),
+              ("hardtan", 12), ("lhtan", 13), ("selu", 14), ("gelu", 15), ("relu", 1))
+
+
+def test_rare_activation_gradients_golden(ops):
+    """gradient() of the 12 rarer activations and gradient_array_swish: the oracle reproduces the
+    reference's gradient_array output on the activation grid bit for bit (tests/golden/ops_grad.npz)."""
+    L = O.lib()
+    gg = np.load(os.path.join(GOLD, "ops_grad.npz"))
+    for name, a in RARE_GRADS:
+        y = np.ascontiguousarray(ops["act_" + name])
+        d = np.ones_like(y)
+        L.orc_gradient_array(O.fptr(y), y.size, a, O.fptr(d))
+        assert np.array_equal(d, gg["grad_" + name]), name
+    y = np.ascontiguousarray(ops["act_swish"])
+    d = np.ones_like(y)
+    L.orc_gradient_array_swish(O.fptr(y), y.size, O.fptr(np.ascontiguousarray(gg["swish_sigmoid"])), O.fptr(d))
+    assert np.array_equal(d, gg["grad_swish"])

@@ -53,10 +53,35 @@ def main():
     torch.cuda.synchronize(); ctx.barrier()
     dt = time.perf_counter() - t0
     rate, tmax = dkdist.aggregate_throughput(ctx, a.batch * a.steps, dt)
+    roofline = None
     if ctx.rank == 0:
-        print(json.dumps({"metric": "images/sec %s train step" % a.cfg, "value": rate, "n_gpus": ctx.world,
+        # dominant conv-family kernel of the step (forward convs, data gradients, weight gradients):
+        # algorithmic FLOPs / HIP-event time on the kernel's own stream
+        C = dk.C
+        L.dk_conv_kernel_name.restype = C.c_char_p
+        L.dk_conv_kernel_name.argtypes = [C.c_int]
+        L.dk_profile_enable(1)
+        for _ in range(2):
+            tr.step(x, truth)
+        out = (C.c_double * (3 * 512))()
+        n = L.dk_profile_read(out, 512)
+        L.dk_profile_enable(0)
+        rows = sorted([(out[3 * i + 2], out[3 * i], out[3 * i + 1], i) for i in range(min(n, 512)) if out[3 * i] > 0], reverse=True)
+        ms, launches, gflop, ci = rows[0]
+        tot_ms, tot_gf = sum(r[0] for r in rows), sum(r[2] for r in rows)
+        roofline = {"bound": "mfma", "achieved": gflop / ms, "peak": 157.3, "unit": "TFLOP/s", "frac": gflop / ms / 157.3,
+                    "traffic": None, "kernel": L.dk_conv_kernel_name(ci).decode(), "launches_per_step": launches / 2,
+                    "avg_launch_ms": ms / launches,
+                    "all_conv_kernels": {"achieved": tot_gf / tot_ms, "ms_per_step": tot_ms / 2, "gflop_per_step": tot_gf / 2},
+                    "kernels": [{"kernel": L.dk_conv_kernel_name(r[3]).decode(), "ms_per_step": r[0] / 2, "launches_per_step": r[1] / 2,
+                                 "tflops": r[2] / r[0]} for r in rows[:10]]}
+        gf_img = {"yolov4": 128.459, "yolov4-tiny": 6.910, "yolov4-csp": 77.003}.get(a.cfg)
+        print(json.dumps({"metric": "images/sec %s train step" % a.cfg, "value": rate, "unit": "images/sec", "n_gpus": ctx.world,
                           "ms_per_step": 1000 * tmax / a.steps, "batch_per_gpu": a.batch, "last_cost": cost,
-                          "grad_bucket_mfloats": tr.bucket.numel() / 1e6}))
+                          "frac_of_fp32_mfma_roofline": (rate * 3 * gf_img * 1e9 / (ctx.world * 157.3e12)) if gf_img else None,
+                          "config": {"workload": "%s.cfg %dx%d batch=%d/GPU train step (forward with batch statistics, host yolo loss, "
+                                                 "backward, gradient all-reduce, SGD)" % (a.cfg, net.w, net.h, a.batch)},
+                          "grad_bucket_mfloats": tr.bucket.numel() / 1e6, "roofline": roofline}))
     net.close(); ctx.close()
 
 

@@ -284,10 +284,93 @@ def yolov4_csp():
     return c.text()
 
 
+def yolov4x_mish(size=512):
+    """scaled-YOLOv4 "x" (yolov4x-mish, BASELINE configs[4]): the yolov4-csp block grammar at width
+    x1.25 and depth x1.33 -- stem 32 / 80, CSP stages (half width, residual units) (80,3) (160,10)
+    (320,10) (640,5), CSP-SPP at 640, PAN blocks with THREE (1x1, 3x3) pairs, heads 320 / 640 / 1280.
+    Written from the public architecture description; there is no network access to diff it against
+    the upstream file, so the invariants printed by tools/make_golden.py cfgcheck (layer count,
+    BFLOPS, weight bytes, from the reference's own parser) are this repo's record, not upstream's."""
+    c = Cfg()
+    c.net(size, size)
+    M = "mish"
+    c.conv(32, 3, 1, M)
+    c.conv(80, 3, 2, M)
+    c.conv(40, 1, 1, M)
+    c.conv(80, 3, 1, M)
+    c.shortcut(-3)
+    stage_out = []
+    for f, n in ((80, 3), (160, 10), (320, 10), (640, 5)):
+        csp_stage(c, f, n, M)
+        stage_out.append(c.n - 1)
+    p3, p4 = stage_out[1], stage_out[2]   # stride-8 and stride-16 backbone outputs
+    # CSP-SPP
+    c.conv(640, 1, 1, M)
+    c.route(-2)
+    c.conv(640, 1, 1, M)
+    c.conv(640, 3, 1, M)
+    c.conv(640, 1, 1, M)
+    c.maxpool(5, 1)
+    c.route(-2)
+    c.maxpool(9, 1)
+    c.route(-4)
+    c.maxpool(13, 1)
+    c.route(-1, -3, -5, -6)
+    c.conv(640, 1, 1, M)
+    c.conv(640, 3, 1, M)
+    c.route(-1, -13)
+    spp = c.conv(640, 1, 1, M)
+    PAIRS = 3
+
+    def csp_neck(f):
+        """[1x1 f] [route -2] [1x1 f] PAIRS x ([3x3 f] ... ) [route] [1x1 f]"""
+        c.conv(f, 1, 1, M)
+        c.route(-2)
+        c.conv(f, 1, 1, M)
+        for k in range(PAIRS):
+            c.conv(f, 3, 1, M)
+            if k + 1 < PAIRS:
+                c.conv(f, 1, 1, M)
+        c.route(-1, -(2 * PAIRS + 2))
+        return c.conv(f, 1, 1, M)
+
+    ups = []
+    for f, lat in ((320, p4), (160, p3)):
+        c.conv(f, 1, 1, M)
+        c.upsample(2)
+        c.route(lat)
+        c.conv(f, 1, 1, M)
+        c.route(-1, -3)
+        c.conv(f, 1, 1, M)
+        ups.append(csp_neck(f))
+    ykw = dict(jitter=.1, scale_x_y=2.0, ignore_thresh=.7, truth_thresh=1,
+               iou_thresh=0.2, cls_normalizer=0.5, iou_normalizer=0.05,
+               iou_loss="ciou", nms_kind="diounms", beta_nms=0.6, max_delta=2)
+
+    def head(f, mask):
+        c.conv(f, 3, 1, M)
+        c.conv(255, 1, 1, "logistic", bn=0)
+        c.yolo(mask, V4_ANCHORS, 9, **ykw)
+
+    def down(f, lateral):
+        c.route(-4)               # the neck block output below the head
+        c.conv(f, 3, 2, M)
+        c.route(-1, lateral)      # absolute index of the same-resolution top-down block
+        c.conv(f, 1, 1, M)
+        return csp_neck(f)
+
+    head(320, (0, 1, 2))
+    down(320, ups[0])
+    head(640, (3, 4, 5))
+    down(640, spp)
+    head(1280, (6, 7, 8))
+    return c.text()
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     for name, fn in (("yolov4-tiny.cfg", yolov4_tiny), ("yolov4.cfg", yolov4),
-                     ("yolov4-csp.cfg", yolov4_csp)):
+                     ("yolov4-csp.cfg", yolov4_csp), ("yolov4x-mish.cfg", yolov4x_mish)):
         with open(os.path.join(OUT, name), "w") as f:
             f.write(fn())
         print("wrote", name)

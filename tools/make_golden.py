@@ -256,6 +256,7 @@ def main():
     gen_yololoss()
     gen_extra()
     gen_map()
+    gen_grads()
 
 
 def gen_train(name="yolov4-tiny", B=2):
@@ -364,6 +365,103 @@ def gen_yololoss():
         rn.close()
     np.savez_compressed(os.path.join(GOLD, "yololoss.npz"), **out)
     print("yololoss.npz")
+
+
+def gen_grads():
+    """gradient_array of the REAL reference for the 12 rarer activations and swish on the outputs of
+    the activation grid already in ops.npz -> ops_grad.npz (delta = 1 going in)."""
+    L = reflib.lib("canon")
+    ops = np.load(os.path.join(GOLD, "ops.npz"))
+    out = {}
+    for name, a in (("relu6", 2), ("relie", 3), ("ramp", 5), ("tanh", 6), ("plse", 7), ("elu", 9), ("loggy", 10),
+                    ("hardtan", 12), ("lhtan", 13), ("selu", 14), ("gelu", 15), ("relu", 1)):
+        y = np.ascontiguousarray(ops["act_" + name])
+        d = np.ones_like(y)
+        L.gradient_array(fp(y), y.size, a, fp(d))
+        out["grad_" + name] = d
+    # swish: gradient_array_swish(x = swish output, sigmoid)
+    grid = np.ascontiguousarray(ops["act_grid"])
+    x = grid.copy()
+    sig = np.zeros_like(x)
+    y = np.zeros_like(x)
+    L.activate_array_swish.argtypes = [FP, C.c_int, FP, FP]
+    L.activate_array_swish(fp(x), x.size, fp(sig), fp(y))
+    d = np.ones_like(grid)
+    L.gradient_array_swish.argtypes = [FP, C.c_int, FP, FP]
+    L.gradient_array_swish(fp(y), y.size, fp(sig), fp(d))
+    out["grad_swish"], out["swish_sigmoid"] = d, sig
+    np.savez_compressed(os.path.join(GOLD, "ops_grad.npz"), **out)
+    print("ops_grad.npz:", sorted(out))
+
+
+def gen_train_big(name="yolov4", B=8):
+    """BASELINE config C4 per GPU: one yolov4 608x608 train step at batch 8 through the REAL reference
+    -> train_<cfg>_b<B>.npz with SUMMARIES only (per layer: sum, sum of squares and 64 strided samples
+    of the train-mode output; per conv: the same of weight/scale updates and delta; cost; yolo deltas
+    sparse).  The reference run is finished and freed before the oracle runs (the two do not fit in
+    memory together at this size); the oracle must reproduce every summary bit for bit."""
+    import gc
+    cfg_txt = open(os.path.join(ROOT, "cfg", name + ".cfg")).read().replace("batch=64", "batch=%d" % B).replace("subdivisions=8", "subdivisions=1")
+    cfg = f"/tmp/_dk_{name}_b{B}.cfg"
+    open(cfg, "w").write(cfg_txt)
+    net = O.parse_cfg(cfg)
+    convs = [(l.n, l.c // l.groups, l.size, l.batch_normalize) for l in net.layers if l.type == O.CONVOLUTIONAL]
+    wpath = f"/tmp/_dk_{name}.weights"
+    synth.write_weights(wpath, convs, seed=2024)
+    x = synth.make_input(B, net.c, net.h, net.w, seed=12345)
+    truth = np.zeros((B, 90 * 5), np.float32)
+    boxes = [(.3, .4, .2, .3, 1), (.6, .5, .4, .35, 17), (.8, .2, .1, .15, 60), (.05, .93, .08, .1, 3), (.5, .5, .9, .8, 79)]
+    for b in range(B):
+        for t, box in enumerate(boxes[b % 5:] + boxes[:b % 5]):
+            truth[b, t * 5:(t + 1) * 5] = box
+
+    def summ(a, k=64):
+        a = np.asarray(a).ravel()
+        idx = np.linspace(0, a.size - 1, k).astype(np.int64)
+        return np.concatenate([[np.sum(a, dtype=np.float64), np.sum(a.astype(np.float64) ** 2)], a[idx].astype(np.float64)])
+    rn = reflib.RefNet(cfg, wpath, train=True)
+    assert rn.batch == B
+    rn.L.ref_set_max_iter(rn.p, 1000)
+    cost = rn.L.ref_train_datum(rn.p, fp(x), fp(truth))
+    out = {"batch": np.int32(B), "truth": truth, "cost": np.float32(cost)}
+    fwd, grads, ydelta = [], [], {}
+    for i in range(rn.n):
+        inf = rn.info(i)
+        fwd.append(np.concatenate([[i], summ(rn.output(i))]))
+        if inf["type"] == O.YOLO:
+            d = rn.arr(i, 6, inf["batch"] * inf["outputs"])
+            nz = np.flatnonzero(d)
+            out[f"yolo_{i}_delta_idx"], out[f"yolo_{i}_delta_val"] = nz.astype(np.int64), d[nz]
+            ydelta[i] = d
+        if inf["type"] == O.CONVOLUTIONAL:
+            for which, n in ((7, inf["nweights"]), (8, inf["n"]), (9, inf["n"])):
+                r = rn.arr(i, which, n)
+                if r is not None and not (which == 9 and not inf["batch_normalize"]):
+                    grads.append(np.concatenate([[i, which], summ(r, 16)]))
+            grads.append(np.concatenate([[i, 6], summ(rn.arr(i, 6, inf["batch"] * inf["outputs"]), 16)]))
+    out["fwd_summaries"], out["grad_summaries"] = np.array(fwd), np.array(grads)
+    rn.close()
+    del rn
+    gc.collect()
+    print("reference done, cost", cost, flush=True)
+    np.savez_compressed(os.path.join(GOLD, f"train_{name}_b{B}.npz"), **out)   # kept even if the oracle check below is interrupted
+    onet = O.load_network_train(cfg, wpath, None)
+    O.forward_train(onet, x)
+    for i, l in enumerate(onet.layers):
+        assert np.array_equal(summ(l.output), out["fwd_summaries"][i][1:]), f"big train forward: oracle != reference at {i}"
+        if l.type == O.YOLO:
+            l.delta[...] = ydelta[i].reshape(l.delta.shape)
+    print("oracle forward matches", flush=True)
+    O.backward(onet)
+    gi = {(int(r[0]), int(r[1])): r[2:] for r in out["grad_summaries"]}
+    for i, l in enumerate(onet.layers):
+        if l.type != O.CONVOLUTIONAL:
+            continue
+        assert np.array_equal(summ(l.weight_updates, 16), gi[(i, 7)]), f"big train backward: weight_updates at {i}"
+        if l.batch_normalize:
+            assert np.array_equal(summ(l.scale_updates, 16), gi[(i, 9)]), f"big train backward: scale_updates at {i}"
+        assert np.array_equal(summ(l.delta, 16), gi[(i, 6)]), f"big train backward: delta at {i}"
+    print(f"train_{name}_b{B}.npz: cost {cost:.4f}; oracle == reference on every summary")
 
 
 se_cfgs = synth.se_cfgs
@@ -521,6 +619,10 @@ def gen_map(name="yolov4-tiny", K=4):
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "map":
         gen_map()
+    elif len(sys.argv) > 1 and sys.argv[1] == "grads":
+        gen_grads()
+    elif len(sys.argv) > 1 and sys.argv[1] == "train_big":
+        gen_train_big(sys.argv[2] if len(sys.argv) > 2 else "yolov4", int(sys.argv[3]) if len(sys.argv) > 3 else 8)
     elif len(sys.argv) > 1 and sys.argv[1] == "extra":
         gen_extra()
     elif len(sys.argv) > 1 and sys.argv[1] == "train":
