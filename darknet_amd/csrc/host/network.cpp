@@ -42,6 +42,7 @@ void DkNetSetPullHeads(Network* net, int on) { net->opt_pull_heads = on < 0 ? 0 
 static bool net_graph(const Network* net) { return net->opt_graph ? net->opt_graph == 2 : g_dk_graph != 0; }
 static bool net_pull_heads(const Network* net) { return net->opt_pull_heads ? net->opt_pull_heads == 2 : g_dk_pull_heads != 0; }
 void DkFreeDpState(Network* net);
+void DkInvalidateSgdPlan(Network* net);
 
 // ---------------------------------------------------------------------------
 int GetNetworkInputSize(Network* net) { return net->layers[0].inputs; }
@@ -660,10 +661,14 @@ void DkNetworkPredictU8(Network* net, const unsigned char* frames_hwc, size_t ro
 // scan does (layer, anchor, cell) and applies the reference's box arithmetic on the host:
 // same Detection arrays, ~100 KB instead of the whole head across PCIe.
 // ---------------------------------------------------------------------------
-static void ensure_candidates(Network* net, float thresh)
+// nms <= 0: raw candidates (class scores as decoded); nms > 0: NmsSort applied on the device
+// (dk_nms_records), the records then hold boxes and post-NMS probabilities
+static void ensure_candidates(Network* net, float thresh, float nms = 0.f)
 {
-  if (net->cand_valid && net->cand_seq == net->predict_seq && net->cand_thresh == thresh)
+  if (net->cand_valid && net->cand_seq == net->predict_seq && net->cand_thresh == thresh && net->cand_nms == nms)
     return;
+  net->cand_nms = nms;
+  net->cand_nms_done = 0;
   int classes = -1;
   bool uniform = true;
   for (int i = 0; i < net->n; ++i)
@@ -710,6 +715,43 @@ static void ensure_candidates(Network* net, float thresh)
     }
     CHECK_HIP(hipMemcpyAsync(&count, net->cand_counter_gpu, sizeof(int), hipMemcpyDeviceToHost, st));
     CHECK_HIP(hipStreamSynchronize(st));
+    if (nms > 0 && count > 0 && count <= net->cand_cap)
+    {
+      // per-layer decode parameters, once
+      if (!net->nms_heads_gpu)
+      {
+        std::vector<DkYoloHead> hh(net->n);
+        memset(hh.data(), 0, sizeof(DkYoloHead) * net->n);
+        for (int i = 0; i < net->n; ++i)
+        {
+          const layer* l = &net->layers[i];
+          if (l->type != YOLO)
+            continue;
+          if (l->n > 8)
+            error("device NMS: more than 8 anchors per yolo layer");
+          hh[i].lw = l->w; hh[i].lh = l->h;
+          for (int n = 0; n < l->n; ++n)
+          {
+            hh[i].anchor_w[n] = l->biases[2 * l->mask[n]];
+            hh[i].anchor_h[n] = l->biases[2 * l->mask[n] + 1];
+          }
+        }
+        CHECK_HIP(hipMalloc(&net->nms_heads_gpu, sizeof(DkYoloHead) * net->n + sizeof(int)));
+        CHECK_HIP(hipMemcpy(net->nms_heads_gpu, hh.data(), sizeof(DkYoloHead) * net->n, hipMemcpyHostToDevice));
+      }
+      int* overflow_gpu = (int*)((char*)net->nms_heads_gpu + sizeof(DkYoloHead) * net->n);
+      CHECK_HIP(hipMemsetAsync(overflow_gpu, 0, sizeof(int), st));
+      const layer* last = &net->layers[net->n - 1];
+      if (dk_nms_records(net->cand_gpu, count, classes, (const DkYoloHead*)net->nms_heads_gpu, net->w, net->h, net->batch,
+              thresh, nms, (int)last->nms_kind, last->beta_nms, overflow_gpu, st))
+        error("dk_nms_records failed");
+      int overflow = 0;
+      CHECK_HIP(hipMemcpyAsync(&overflow, overflow_gpu, sizeof(int), hipMemcpyDeviceToHost, st));
+      CHECK_HIP(hipStreamSynchronize(st));
+      if (overflow)
+        error("device NMS: more than 4096 live candidates for one (image, class); use GetNetworkBoxes + NmsSort");
+      net->cand_nms_done = 1;
+    }
   }
   if (!uniform || count > net->cand_cap)
   {
@@ -764,21 +806,30 @@ static int candidates_to_dets(Network* net, int b, float thresh, Detection* dets
       const int n = loc / wh, i = loc - n * wh;
       const int col = i % l->w, row = i / l->w;
       const int a = l->mask[n];
-      // GetYoloBox, yolo_layer.cpp:139-148 -- the same float operations as DkGetYoloDetectionsBatch
-      Box bx;
-      bx.x = (col + v[0]) / l->w;
-      bx.y = (row + v[1]) / l->h;
-      bx.w = expf(v[2]) * l->biases[2 * a] / net->w;
-      bx.h = expf(v[3]) * l->biases[2 * a + 1] / net->h;
       const float objectness = v[4];
+      Box bx;
+      if (net->cand_nms_done)
+      {
+        // the device already decoded the box and applied threshold + NMS to the probabilities
+        bx.x = v[0]; bx.y = v[1]; bx.w = v[2]; bx.h = v[3];
+        for (int j = 0; j < l->classes; ++j) dets[out].prob[j] = v[5 + j];
+      }
+      else
+      {
+        // GetYoloBox, yolo_layer.cpp:139-148 -- the same float operations as DkGetYoloDetectionsBatch
+        bx.x = (col + v[0]) / l->w;
+        bx.y = (row + v[1]) / l->h;
+        bx.w = expf(v[2]) * l->biases[2 * a] / net->w;
+        bx.h = expf(v[3]) * l->biases[2 * a + 1] / net->h;
+        for (int j = 0; j < l->classes; ++j)
+        {
+          const float prob = objectness * v[5 + j];
+          dets[out].prob[j] = (prob > thresh) ? prob : 0;
+        }
+      }
       dets[out].bbox = bx;
       dets[out].objectness = objectness;
       dets[out].classes = l->classes;
-      for (int j = 0; j < l->classes; ++j)
-      {
-        const float prob = objectness * v[5 + j];
-        dets[out].prob[j] = (prob > thresh) ? prob : 0;
-      }
       if (ids)
       {
         ids[4 * out + 0] = tag;
@@ -848,6 +899,65 @@ Detection* GetNetworkBoxesBatch(Network* net, int b, float thresh, int* num)
 Detection* GetNetworkBoxes(Network* net, float thresh, int* num)
 {
   return GetNetworkBoxesBatch(net, 0, thresh, num);
+}
+
+// GetNetworkBoxes + NmsSort in one call with the suppression done on the device;
+// needs the heads in HBM (DkSetPullHeads(0) / DkNetSetPullHeads(net, 0)).  The array holds every
+// candidate of image b in scan order with its post-NMS probabilities (NmsSort's final re-ordering by
+// the last class is not reproduced).
+Detection* DkGetNetworkBoxesNms(Network* net, int b, float thresh, float nms, int* num)
+{
+  if (b < 0 || b >= net->batch)
+    error("DkGetNetworkBoxesNms: batch index out of range");
+  if (!heads_on_device(net))
+    error("DkGetNetworkBoxesNms: the heads must stay on the device (DkSetPullHeads(0))");
+  ensure_candidates(net, thresh, nms);
+  if (net->cand_fallback)
+  {
+    Detection* dets = GetNetworkBoxesBatch(net, b, thresh, num);
+    const layer* last = &net->layers[net->n - 1];
+    NmsSort(dets, *num, last->classes, nms, last->nms_kind, last->beta_nms);
+    return dets;
+  }
+  const int n = candidates_to_dets(net, b, thresh, nullptr, nullptr, 0);
+  if (num)
+    *num = n;
+  const int classes = net->cand_rec - 8;
+  Detection* dets = (Detection*)xcalloc(n > 0 ? n : 1, sizeof(Detection));
+  for (int i = 0; i < n; ++i) dets[i].prob = (float*)xcalloc(classes, sizeof(float));
+  candidates_to_dets(net, b, thresh, dets, nullptr, n);
+  return dets;
+}
+
+// flat form: out[k] = [x, y, w, h, objectness, prob[classes]] post-NMS, ids[k] = [layer, anchor, row, col]
+int DkGetBoxesBatchNms(Network* net, int b, float thresh, float nms, float* out, int* ids, int max_dets)
+{
+  if (b < 0 || b >= net->batch || !heads_on_device(net))
+    return -1;
+  ensure_candidates(net, thresh, nms);
+  if (net->cand_fallback)
+    return -2;
+  const int num = candidates_to_dets(net, b, thresh, nullptr, nullptr, 0);
+  if (num == 0)
+    return 0;
+  const int classes = net->cand_rec - 8;
+  Detection* dets = (Detection*)xcalloc(num, sizeof(Detection));
+  for (int k = 0; k < num; ++k) dets[k].prob = (float*)xcalloc(classes, sizeof(float));
+  int* lid = (int*)xcalloc((size_t)num * 4, sizeof(int));
+  candidates_to_dets(net, b, thresh, dets, lid, num);
+  const int rec = 5 + classes;
+  for (int k = 0; k < num && k < max_dets; ++k)
+  {
+    float* o = out + (size_t)k * rec;
+    o[0] = dets[k].bbox.x; o[1] = dets[k].bbox.y; o[2] = dets[k].bbox.w; o[3] = dets[k].bbox.h;
+    o[4] = dets[k].objectness;
+    memcpy(o + 5, dets[k].prob, classes * sizeof(float));
+    if (ids)
+      memcpy(ids + (size_t)k * 4, lid + (size_t)k * 4, 4 * sizeof(int));
+  }
+  FreeDetections(dets, num);
+  free(lid);
+  return num;
 }
 
 void FreeDetections(Detection* dets, int n)
@@ -953,6 +1063,7 @@ void FreeNetwork(Network* net)
   for (int i = 0; i < net->n; ++i) free_layer(&net->layers[i], false);
   if (net->gpu_index >= 0)
   {
+    DkInvalidateSgdPlan(net);
     DkFreeDpState(net);
     if (net->fwd_done_ev) (void)hipEventDestroy((hipEvent_t)net->fwd_done_ev);
     if (net->copy_done_ev) (void)hipEventDestroy((hipEvent_t)net->copy_done_ev);
@@ -972,6 +1083,7 @@ void FreeNetwork(Network* net)
     cuda_free(net->delta_arena_gpu);
     cuda_free(net->cand_gpu);
     cuda_free((float*)net->cand_counter_gpu);
+    if (net->nms_heads_gpu) (void)hipFree(net->nms_heads_gpu);
     if (net->cand_host) cuda_free_host(net->cand_host);
     if (net->u8_gpu) (void)hipFree(net->u8_gpu);
     if (net->u8_pinned) (void)hipHostFree(net->u8_pinned);

@@ -12,6 +12,7 @@
 #include <chrono>
 #include <future>
 #include <stdio.h>
+#include <vector>
 #include <stdlib.h>
 #include <string.h>
 
@@ -330,6 +331,61 @@ void BackwardNetworkGpu(Network* net, NetworkState state)
 
 extern "C" LIB_API size_t DkGradBucketSize(Network* net);
 
+// One launch for every conv / batchnorm tensor of the update (the per-layer slots remain for
+// callers of the plugin API).  Used when no layer asks for a per-iteration exception (burnin_update,
+// train_only_bn, dont_update) and loss_scale is 1; rebuilt when gradient pointers move.
+static bool sgd_plan_usable(Network* net)
+{
+  if (net->loss_scale != 1.0f)
+    return false;
+  for (int i = 0; i < net->n; ++i)
+  {
+    const layer* l = &net->layers[i];
+    if (l->burnin_update || l->train_only_bn || l->dont_update)
+      return false;
+    if (l->update_gpu && l->update_gpu != UpdateConvolutionalLayerGpu && l->update_gpu != UpdateBatchnormLayerGpu)
+      return false;
+  }
+  return true;
+}
+
+static void build_sgd_plan(Network* net)
+{
+  std::vector<float*> w, wu;
+  std::vector<size_t> cnt;
+  std::vector<float> sc;
+  std::vector<int> dec;
+  auto add = [&](float* a, float* b, size_t n, float s, int d) {
+    if (a && b && n)
+    {
+      w.push_back(a); wu.push_back(b); cnt.push_back(n); sc.push_back(s); dec.push_back(d);
+    }
+  };
+  for (int i = 0; i < net->n; ++i)
+  {
+    layer* l = &net->layers[i];
+    if (l->type == CONVOLUTIONAL && l->update_gpu)
+    {
+      add(l->weights_gpu, l->weight_updates_gpu, l->nweights, l->learning_rate_scale, 1);
+      add(l->biases_gpu, l->bias_updates_gpu, l->n, l->learning_rate_scale, 0);
+      add(l->scales_gpu, l->scale_updates_gpu, l->n, l->learning_rate_scale, 0);
+    }
+    else if (l->type == BATCHNORM && l->update_gpu)
+    {
+      add(l->biases_gpu, l->bias_updates_gpu, l->c, l->learning_rate_scale, 0);
+      add(l->scales_gpu, l->scale_updates_gpu, l->c, l->learning_rate_scale, 0);
+    }
+  }
+  dk_sgd_plan_destroy(net->sgd_plan);
+  net->sgd_plan = dk_sgd_plan_create((int)w.size(), w.data(), wu.data(), cnt.data(), sc.data(), dec.data());
+}
+
+void DkInvalidateSgdPlan(Network* net)
+{
+  dk_sgd_plan_destroy(net->sgd_plan);
+  net->sgd_plan = nullptr;
+}
+
 void UpdateNetworkGpu(Network* net)
 {
   cuda_set_device(net->gpu_index);
@@ -337,6 +393,16 @@ void UpdateNetworkGpu(Network* net)
   const int actual_batch = net->batch * net->subdiv * (net->grad_replicas > 1 ? net->grad_replicas : 1);
   const int iter = net->curr_iter;
   const float lr = GetCurrLr(net);
+  static const bool multi = !(getenv("DK_SGD_MULTI") && !atoi(getenv("DK_SGD_MULTI")));
+  if (multi && sgd_plan_usable(net))
+  {
+    if (!net->sgd_plan)
+      build_sgd_plan(net);
+    dk_sgd_update_multi(net->sgd_plan, actual_batch, lr, net->momentum, net->decay, get_cuda_stream());
+    if (net->grad_replicas > 1 && net->grad_bucket)
+      dk_scal(DkGradBucketSize(net), 1.0f / net->grad_replicas, net->grad_bucket, get_cuda_stream());
+    return;
+  }
   for (int i = 0; i < net->n; ++i)
   {
     layer* l = &net->layers[i];
@@ -538,6 +604,7 @@ extern "C" LIB_API void DkAttachGradBucket(Network* net, float* bucket)
       move(&l->scale_updates_gpu, l->n);
   }
   net->grad_bucket = bucket;
+  DkInvalidateSgdPlan(net);   // the gradient tensors moved
 }
 
 // B = batch * subdivisions * replicas in the update (each replica contributes its sub-batches,

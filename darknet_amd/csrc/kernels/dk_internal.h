@@ -56,3 +56,9 @@ bool dk_prof_on();
 int dk_prof_named_slot(const char* kernel_name);
 void dk_prof_begin(DkProfScope& s, void* stream);
 void dk_prof_end(DkProfScope& s, void* stream, int slot, double gflop);
+
+// multi-tensor SGD (train_ops.hip): one launch for every tensor of UpdateNetworkGpu
+void* dk_sgd_plan_create(int ntensors, float* const* weights, float* const* updates, const size_t* counts,
+    const float* lr_scales, const int* use_decay);
+void dk_sgd_plan_destroy(void* plan);
+int dk_sgd_update_multi(void* plan, int batch, float learning_rate, float momentum, float decay, void* stream);

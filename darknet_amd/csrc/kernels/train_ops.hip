@@ -21,6 +21,7 @@
 // finalize kernel); the summation order differs from the CPU's sequential fp32
 // loop -- see tests/util.py TRAIN_ATOL_RMS.
 #include <hip/hip_runtime.h>
+#include <vector>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -42,7 +43,9 @@ inline int grid_for(size_t work, int threads = 256)
 
 constexpr int RT = 512;  // threads per reduction workgroup
 
-// per-device fp64 scratch for the two-stage channel reductions (4 doubles per channel)
+// per-device fp64 scratch for the two-stage channel reductions (4 doubles per channel).
+// Zero on entry by contract: it is cleared once when allocated and every finalize kernel clears
+// the entries it has consumed, so no per-call memset is needed (there used to be ~300 per step).
 double* chan_scratch(int filters, hipStream_t st)
 {
   static double* buf[16];
@@ -51,11 +54,14 @@ double* chan_scratch(int filters, hipStream_t st)
   if (cap[dev] < filters)
   {
     if (buf[dev])
+    {
+      CHECK_HIP(hipStreamSynchronize(st));
       CHECK_HIP(hipFree(buf[dev]));
+    }
     cap[dev] = filters < 4096 ? 4096 : filters;
     CHECK_HIP(hipMalloc((void**)&buf[dev], (size_t)cap[dev] * 4 * sizeof(double)));
+    CHECK_HIP(hipMemsetAsync(buf[dev], 0, (size_t)cap[dev] * 4 * sizeof(double), st));
   }
-  CHECK_HIP(hipMemsetAsync(buf[dev], 0, (size_t)filters * 4 * sizeof(double), st));
   return buf[dev];
 }
 
@@ -131,7 +137,7 @@ __global__ void __launch_bounds__(RT) bn_partial_kernel(const float* __restrict_
   }
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ scratch, int batch, int filters,
+__global__ void bn_finalize_kernel(double* __restrict__ scratch, int batch, int filters,
     int spatial, float* __restrict__ mean, float* __restrict__ variance,
     float* __restrict__ rolling_mean, float* __restrict__ rolling_variance)
 {
@@ -140,6 +146,8 @@ __global__ void bn_finalize_kernel(const double* __restrict__ scratch, int batch
     return;
   const double n = (double)batch * spatial;
   const double s = scratch[2 * f], q = scratch[2 * f + 1];
+  scratch[2 * f] = 0;   // leave the scratch zeroed for the next reduction
+  scratch[2 * f + 1] = 0;
   const float m = (float)(s / n);
   double v = (q - s * s / n) / (n - 1);
   if (v < 0)
@@ -247,7 +255,7 @@ __global__ void __launch_bounds__(RT) chan_partial_kernel(const float* __restric
   }
 }
 
-__global__ void chan_finalize_kernel(const double* __restrict__ scratch,
+__global__ void chan_finalize_kernel(double* __restrict__ scratch,
     const float* __restrict__ variance, int filters, float* __restrict__ bias_updates,
     float* __restrict__ scale_updates, float* __restrict__ mean_delta,
     float* __restrict__ variance_delta, int mode)
@@ -255,16 +263,21 @@ __global__ void chan_finalize_kernel(const double* __restrict__ scratch,
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= filters)
     return;
+  const double s0 = scratch[4 * f + 0], s1 = scratch[4 * f + 1], s2 = scratch[4 * f + 2], s3 = scratch[4 * f + 3];
+  scratch[4 * f + 0] = 0;   // leave the scratch zeroed for the next reduction
+  scratch[4 * f + 1] = 0;
+  scratch[4 * f + 2] = 0;
+  scratch[4 * f + 3] = 0;
   if (bias_updates)
-    bias_updates[f] += (float)scratch[4 * f + 0];
+    bias_updates[f] += (float)s0;
   if (mode)
   {
-    scale_updates[f] += (float)scratch[4 * f + 1];
+    scale_updates[f] += (float)s1;
     const float var = variance[f];
-    float md = (float)scratch[4 * f + 2];
+    float md = (float)s2;
     md *= (-1. / sqrtf(var + .00001f));
     mean_delta[f] = md;
-    float vd = (float)scratch[4 * f + 3];
+    float vd = (float)s3;
     vd *= -.5 * powf(var + .00001f, (float)(-3. / 2.));
     variance_delta[f] = vd;
   }
@@ -485,6 +498,42 @@ __global__ void sgd_kernel(float* __restrict__ w, float* __restrict__ wu, size_t
   }
 }
 
+// The same update for MANY tensors in one launch (UpdateNetworkGpu: ~330 tensors per step, most
+// of them a few hundred floats -- one launch each is pure launch overhead).  Work is cut into
+// chunks of SGD_CHUNK elements; chunk c belongs to tensor ent[c].x starting at element ent[c].y.
+constexpr int SGD_CHUNK = 4096;
+struct DkSgdTensor
+{
+  float* w;
+  float* wu;
+  unsigned long long n;
+  float lr_scale;     // the layer's learning_rate_scale
+  int use_decay;
+};
+
+__global__ void sgd_multi_kernel(const DkSgdTensor* __restrict__ tensors, const int2* __restrict__ chunks,
+    float decay_b, float lr_init, int batch, float momentum)
+{
+  const int2 ch = chunks[blockIdx.x];
+  const DkSgdTensor t = tensors[ch.x];
+  const size_t lo = (size_t)ch.y * SGD_CHUNK;
+  size_t hi = lo + SGD_CHUNK;
+  if (hi > t.n)
+    hi = t.n;
+  const float lr = (lr_init * t.lr_scale) / batch;   // the per-layer path's float operations, in its order
+  for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x)
+  {
+    float u = t.wu[i];
+    float x = t.w[i];
+    if (t.use_decay)
+      u += decay_b * x;
+    x += lr * u;
+    u *= momentum;
+    t.w[i] = x;
+    t.wu[i] = u;
+  }
+}
+
 // Wt[c][(m, t)] = W[m][c][t]  (t = kh*size + kw), per group
 __global__ void transpose_w_kernel(const float* __restrict__ w, float* __restrict__ wt, int M, int C,
     int ss, size_t total, int flip)
@@ -669,6 +718,61 @@ extern "C" int dk_sgd_update(float* weights, float* weight_updates, size_t n, in
     return 0;
   hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), weights,
       weight_updates, n, -decay * batch, learning_rate / batch, momentum, use_decay);
+  CHECK_HIP(hipPeekAtLastError());
+  return 0;
+}
+
+// Multi-tensor form: `plan` is an opaque device-side plan built by dk_sgd_plan_create from host
+// arrays (weights[i], updates[i], counts[i], lr_scales[i], use_decay[i]); the float operations per
+// element are exactly dk_sgd_update's with learning_rate * lr_scale[i] (computed in float: the
+// reference multiplies learning_rate_init * l->learning_rate_scale in float before dividing by batch).
+struct DkSgdPlan
+{
+  DkSgdTensor* tensors;
+  int2* chunks;
+  int nchunks;
+};
+
+void* dk_sgd_plan_create(int ntensors, float* const* weights, float* const* updates, const size_t* counts,
+    const float* lr_scales, const int* use_decay)
+{
+  std::vector<DkSgdTensor> ht(ntensors);
+  std::vector<int2> hc;
+  for (int i = 0; i < ntensors; ++i)
+  {
+    ht[i].w = weights[i];
+    ht[i].wu = updates[i];
+    ht[i].n = counts[i];
+    ht[i].lr_scale = lr_scales[i];
+    ht[i].use_decay = use_decay[i];
+    for (size_t c = 0; c * SGD_CHUNK < counts[i]; ++c) hc.push_back(make_int2(i, (int)c));
+  }
+  DkSgdPlan* p = new DkSgdPlan();
+  p->nchunks = (int)hc.size();
+  CHECK_HIP(hipMalloc((void**)&p->tensors, sizeof(DkSgdTensor) * (ntensors > 0 ? ntensors : 1)));
+  CHECK_HIP(hipMalloc((void**)&p->chunks, sizeof(int2) * (hc.size() ? hc.size() : 1)));
+  CHECK_HIP(hipMemcpy(p->tensors, ht.data(), sizeof(DkSgdTensor) * ntensors, hipMemcpyHostToDevice));
+  CHECK_HIP(hipMemcpy(p->chunks, hc.data(), sizeof(int2) * hc.size(), hipMemcpyHostToDevice));
+  return p;
+}
+
+void dk_sgd_plan_destroy(void* plan)
+{
+  DkSgdPlan* p = (DkSgdPlan*)plan;
+  if (!p)
+    return;
+  (void)hipFree(p->tensors);
+  (void)hipFree(p->chunks);
+  delete p;
+}
+
+int dk_sgd_update_multi(void* plan, int batch, float learning_rate, float momentum, float decay, void* stream)
+{
+  DkSgdPlan* p = (DkSgdPlan*)plan;
+  if (!p || !p->nchunks)
+    return 0;
+  hipLaunchKernelGGL(sgd_multi_kernel, dim3(p->nchunks), dim3(256), 0, S(stream), p->tensors, p->chunks,
+      -decay * batch, learning_rate, batch, momentum);
   CHECK_HIP(hipPeekAtLastError());
   return 0;
 }

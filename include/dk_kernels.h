@@ -115,6 +115,20 @@ DK_API int dk_conv_forward_half_packed(const DkConvDesc* d, const float* x, cons
 DK_API int dk_yolo_compact(const float* decoded, int batch, int lw, int lh, int n_anchors,
     int classes, float thresh, int tag, float* records, int* counter, int cap, void* stream);
 
+/* NmsSort on the device (src/box.cpp:393-419 on the boxes of src/yolo_layer.cpp:139-148, :794-834):
+ * `records` are dk_yolo_compact's candidates [tag, image, loc, x, y, w, h, obj, cls...]; on return
+ * x..h hold the box (centre-normalised) and cls[j] the class probability after thresholding
+ * (obj * cls[j] > thresh, else 0) and per-class suppression (nms_kind 0 = greedy IoU, 1 = DIoU with
+ * beta).  heads_dev[tag] describes yolo layer `tag` (device memory).  *overflow_dev is incremented
+ * when one (image, class) has more than 4096 live candidates (the caller then falls back). */
+typedef struct DkYoloHead
+{
+  int lw, lh;
+  float anchor_w[8], anchor_h[8];   /* biases[2 * mask[n]], biases[2 * mask[n] + 1] */
+} DkYoloHead;
+DK_API int dk_nms_records(float* records, int count, int classes, const DkYoloHead* heads_dev, int net_w,
+    int net_h, int batch, float thresh, float nms_thresh, int nms_kind, float beta, int* overflow_dev, void* stream);
+
 /* Mat2Image (src/visualize.cpp:26-55) for `batch` interleaved u8 images of h rows of row_step bytes
  * already in device memory: chw[b][k][y][x] = hwc[b][y*row_step + x*c + k] / 255.0f. */
 DK_API int dk_image_u8_to_chw(const unsigned char* hwc, float* chw, int batch, int w, int h, int c,

@@ -284,6 +284,9 @@ struct Network
   int cand_cap, cand_count, cand_rec, cand_fallback, cand_valid;
   long cand_seq, predict_seq;
   float cand_thresh;
+  float cand_nms;        /* NMS threshold the candidate records were suppressed with on the device (0: raw) */
+  int cand_nms_done;
+  void* nms_heads_gpu;   /* DkYoloHead[n] + overflow word (device NMS) */
   unsigned char* u8_gpu; /* interleaved u8 frames on the device */
   unsigned char* u8_pinned;
   size_t u8_bytes;
@@ -296,6 +299,7 @@ struct Network
   void* copy_done_ev;    /* NetworkPredictDevice: head copies of the previous call finished */
   int copy_pending;
   int opt_graph, opt_pull_heads; /* per-network overrides of DkSetGraph / DkSetPullHeads (0/1), -1... stored +1: 0 = follow the process-wide setting */
+  void* sgd_plan;        /* multi-tensor SGD plan (one launch per update), or NULL */
   int planned;           /* DkPlanInference ran (fusion plan, packed/dual weight copies exist) */
   int backward_stopped;  /* train: a stopbackward layer ended this step's backward sweep (DkBackwardRange segments) */
 };
@@ -494,6 +498,10 @@ LIB_API float* DkLayerHostPtr(Network* net, int i, int which); /* 1 weights 2 bi
 /* Flattened detections of batch item b: per det [x,y,w,h,obj,prob[classes]] and
  * ids [layer, anchor, row, col]; returns the count (writes at most max_dets). */
 LIB_API int DkGetBoxesBatch(Network* net, int b, float thresh, float* dets, int* ids, int max_dets);
+/* GetNetworkBoxes + NmsSort with the suppression on the device (src/box.cpp:393-419; heads must stay
+ * in HBM: DkSetPullHeads(0)): every candidate of image b in scan order with post-NMS probabilities */
+LIB_API Detection* DkGetNetworkBoxesNms(Network* net, int b, float thresh, float nms, int* num);
+LIB_API int DkGetBoxesBatchNms(Network* net, int b, float thresh, float nms, float* dets, int* ids, int max_dets);
 LIB_API size_t DkWeightsFileSize(Network* net);
 
 /* mAP of ValidateDetector (src/detector.cpp:326-562) on flattened inputs: per image n_dets[i]

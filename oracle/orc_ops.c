@@ -448,9 +448,30 @@ void orc_gradient_array_mish(int n, const float* activation_input, float* delta)
 /* --------------------------------------------------------------- batchnorm */
 
 /* mean_cpu, src/blas.c:164-181 */
+/* Analysis switch (NOT the reference's arithmetic): when set, the batch statistics accumulate in
+ * double and are rounded once.  The reference adds up to millions of fp32 terms sequentially into a
+ * float, so ITS statistics carry a summation error that grows with the layer size; comparing both
+ * variants separates that error from any error of the implementation under test
+ * (tests/test_gpu_train.py, tools/make_golden.py train_big). */
+static int g_bn_stats_f64 = 0;
+void orc_set_bn_stats_f64(int on) { g_bn_stats_f64 = on; }
+
 void orc_mean(const float* x, int batch, int filters, int spatial, float* mean)
 {
   float scale = 1. / (batch * spatial);
+  if (g_bn_stats_f64)
+  {
+#pragma omp parallel for
+    for (int i = 0; i < filters; ++i)
+    {
+      double acc = 0;
+      for (int j = 0; j < batch; ++j)
+        for (int k = 0; k < spatial; ++k)
+          acc += x[(size_t)j * filters * spatial + (size_t)i * spatial + k];
+      mean[i] = (float)(acc / ((double)batch * spatial));
+    }
+    return;
+  }
   for (int i = 0; i < filters; ++i)
   {
     mean[i] = 0;
@@ -467,6 +488,22 @@ void orc_variance(const float* x, const float* mean, int batch, int filters,
     int spatial, float* variance)
 {
   float scale = 1. / (batch * spatial - 1);
+  if (g_bn_stats_f64)
+  {
+#pragma omp parallel for
+    for (int i = 0; i < filters; ++i)
+    {
+      double acc = 0;
+      for (int j = 0; j < batch; ++j)
+        for (int k = 0; k < spatial; ++k)
+        {
+          const double d = (double)x[(size_t)j * filters * spatial + (size_t)i * spatial + k] - (double)mean[i];
+          acc += d * d;
+        }
+      variance[i] = (float)(acc / ((double)batch * spatial - 1));
+    }
+    return;
+  }
   for (int i = 0; i < filters; ++i)
   {
     variance[i] = 0;

@@ -276,3 +276,45 @@ def test_resize_network_vs_oracle(gpu, tmp_path):
     for i, h0 in heads0.items():
         assert np.array_equal(net.output(i), h0), "416x416 after resizing there and back differs"
     net.close()
+
+
+@pytest.mark.parametrize("name", ["yolov4-tiny", "yolov4-csp"])
+def test_device_nms_vs_reference_golden(gpu, weights, name):
+    """NmsSort on the device (kernels/nms.hip; greedy IoU for yolov4-tiny, DIoU for
+    yolov4-csp) against the REAL reference's NmsSort result stored in net_<cfg>.npz -- not against the
+    product's host path: same boxes (the device decodes w/h with its own expf: rounding-level
+    tolerance), for every detection the same NUMBER of surviving classes and the same surviving
+    probability mass.  Compared as sets (NmsSort's final ordering by the last class is not part of
+    the result)."""
+    g = np.load(os.path.join(GOLD, "net_%s.npz" % name))
+    L = gpu.lib()
+    L.DkSetPullHeads.argtypes = [C.c_int]
+    L.DkGetBoxesBatchNms.restype = C.c_int
+    L.DkGetBoxesBatchNms.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int]
+    net = netutil.DkNet(gpu, netutil.cfg_path(name), weights[name])
+    x = synth.make_input(1, net.c, net.h, net.w)
+    L.DkSetPullHeads(0)
+    try:
+        net.predict(x)
+        classes = net.info(net.n - 1)["classes"]
+        cap = 400000
+        buf = np.zeros((cap, 5 + classes), np.float32)
+        ids = np.zeros((cap, 4), np.int32)
+        n = L.DkGetBoxesBatchNms(net.p, 0, float(g["thresh"]), float(g["nms_thresh"]), buf.ctypes.data, ids.ctypes.data, cap)
+    finally:
+        L.DkSetPullHeads(1)
+    ref = g["nms_box_obj"]
+    assert n == len(ref), (n, len(ref))
+    d = buf[:n]
+
+    def canon(a):
+        k = np.round(a[:, :4].astype(np.float64), 5)
+        return np.lexsort((k[:, 3], k[:, 2], k[:, 1], k[:, 0]))
+    od, orf = canon(d), canon(ref)
+    util.assert_close(d[od, :5], ref[orf], "%s post-NMS boxes + objectness" % name, rel=2e-6, atol_rms=1e-6)
+    keep = d[od, 5:] > 0
+    assert np.array_equal(keep.sum(1), g["nms_kept_per_det"][orf]), "different classes survive the device NMS"
+    mass = np.where(keep, d[od, 5:], 0).sum(1, dtype=np.float64)
+    assert np.allclose(mass, g["nms_kept_prob_sum"][orf], rtol=2e-5, atol=1e-7)
+    assert keep.sum() < (g["nms_kept_per_det"] >= 0).size * classes   # something was suppressed
+    net.close()

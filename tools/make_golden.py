@@ -461,7 +461,25 @@ def gen_train_big(name="yolov4", B=8):
         if l.batch_normalize:
             assert np.array_equal(summ(l.scale_updates, 16), gi[(i, 9)]), f"big train backward: scale_updates at {i}"
         assert np.array_equal(summ(l.delta, 16), gi[(i, 6)]), f"big train backward: delta at {i}"
-    print(f"train_{name}_b{B}.npz: cost {cost:.4f}; oracle == reference on every summary")
+    print(f"train_{name}_b{B}.npz: cost {cost:.4f}; oracle == reference on every summary", flush=True)
+    # Second forward with the batch statistics accumulated in double (analysis variant, see
+    # orc_set_bn_stats_f64): separates the reference's own fp32 summation error from the error of
+    # an implementation that reduces in higher precision.
+    del onet
+    gc.collect()
+    O.lib().orc_set_bn_stats_f64(1)
+    onet = O.load_network_train(cfg, wpath, None)
+    O.forward_train(onet, x)
+    O.lib().orc_set_bn_stats_f64(0)
+    f64 = np.array([np.concatenate([[i], summ(l.output)]) for i, l in enumerate(onet.layers)])
+    out["fwd_summaries_f64stats"] = f64
+    shift = []
+    for a, b in zip(out["fwd_summaries"], f64):
+        rms = np.sqrt(b[2] / max(1, onet.layers[int(a[0])].batch * onet.layers[int(a[0])].outputs))
+        shift.append(np.abs(a[3:] - b[3:]).max() / rms if rms > 0 else 0.0)
+    out["ref_vs_f64stats_max_over_rms"] = np.array(shift)
+    np.savez_compressed(os.path.join(GOLD, f"train_{name}_b{B}.npz"), **out)
+    print("reference vs fp64-statistics oracle: worst sample shift / rms = %.3g (layer %d)" % (max(shift), int(np.argmax(shift))))
 
 
 se_cfgs = synth.se_cfgs
