@@ -98,6 +98,9 @@ def lib():
         "dk_scal": (i, [sz, f, vp, vp]),
         "dk_profile_enable": (None, [i]),
         "dk_profile_read": (i, [C.POINTER(C.c_double), i]),
+        "dk_conv_wino_weights_size": (sz, [C.POINTER(DkConvDesc)]),
+        "dk_conv_wino_transform_weights": (i, [C.POINTER(DkConvDesc), vp, vp, vp]),
+        "dk_conv_wino_register": (None, [vp, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)
@@ -208,8 +211,9 @@ def conv_out_dims(h, w, size, stride_x, stride_y, pad, dilation=1):
 
 def conv_forward(x, weights, biases, batch, c, h, w, n, size, stride, pad,
                  activation, groups=1, dilation=1, residual=None,
-                 want_act_in=False, stride_y=None):
-    """Host-array convenience wrapper over dk_conv_forward (tests)."""
+                 want_act_in=False, stride_y=None, wino=False):
+    """Host-array convenience wrapper over dk_conv_forward (tests).  wino=True also transforms and
+    registers the Winograd copy of the filters (the caller forces the Winograd configuration)."""
     L = lib()
     sy = stride if stride_y is None else stride_y
     oh, ow = conv_out_dims(h, w, size, stride, sy, pad, dilation)
@@ -219,8 +223,20 @@ def conv_forward(x, weights, biases, batch, c, h, w, n, size, stride, pad,
     dr = DeviceArray(residual) if residual is not None else None
     dy = DeviceArray(n=batch * n * oh * ow)
     da = DeviceArray(n=batch * n * oh * ow) if want_act_in else None
+    du = None
+    if wino:
+        nu = L.dk_conv_wino_weights_size(C.byref(d))
+        if not nu:
+            raise RuntimeError("layer does not take the Winograd kernel")
+        du = DeviceArray(n=nu)
+        if L.dk_conv_wino_transform_weights(C.byref(d), dw.ptr, du.ptr, None):
+            raise RuntimeError("dk_conv_wino_transform_weights failed")
+        L.dk_conv_wino_register(dw.ptr, du.ptr)
     rc = L.dk_conv_forward(C.byref(d), dx.ptr, dw.ptr, db.ptr if db else None,
                            dy.ptr, dr.ptr if dr else None, da.ptr if da else None, None)
+    if du is not None:
+        _sync()
+        L.dk_conv_wino_register(dw.ptr, None)
     if rc != 0:
         raise RuntimeError("dk_conv_forward failed")
     y = dy.numpy().reshape(batch, n, oh, ow)

@@ -184,6 +184,7 @@ void DkConvPrepare(layer* l)
 // Inference (BN folded or no BN): one fused launch.  Train mode with BN is
 // handled in train.cpp (raw GEMM, then batch statistics, then activation).
 void ForwardConvTrainGpu(layer* l, NetworkState state);  // train.cpp
+void DkDropWinograd(layer* l);                            // network.cpp
 void DkYoloTrainDelta(layer* l, NetworkState state);      // train.cpp
 void DkFreeLossTask(layer* l);                            // train.cpp
 
@@ -242,8 +243,10 @@ void ForwardConvolutionalLayerGpu(layer* l, NetworkState state)
       error("ForwardConvolutionalLayerGpu (fp16 operands) failed");
     return;
   }
+  // (the Winograd copy of the filters follows Push/Load, not the optimizer: train passes keep the direct kernels)
+  const int cfg = (state.train && dk_conv_config_is_wino(l->conv_cfg)) ? -1 : l->conv_cfg;
   if (dk_conv_forward_cfg(&d, state.input, l->weights_gpu, l->biases_gpu, out, residual, act_in,
-          get_cuda_stream(), l->conv_cfg, out_ctot))
+          get_cuda_stream(), cfg, out_ctot))
     error("ForwardConvolutionalLayerGpu failed");
 }
 
@@ -291,6 +294,12 @@ void PushConvolutionalLayer(layer* l)
     DkConvDesc d = conv_desc(l);
     if (dk_conv_half_pack_weights(&d, l->weights_gpu, l->weights_half_gpu, st))
       error("PushConvolutionalLayer: re-packing the fp16 weights failed");
+  }
+  if (l->weights_wino_gpu)
+  {
+    DkConvDesc d = conv_desc(l);
+    if (dk_conv_wino_transform_weights(&d, l->weights_gpu, l->weights_wino_gpu, st))
+      error("PushConvolutionalLayer: re-transforming the Winograd filters failed");
   }
   CHECK_HIP(hipStreamSynchronize(st));
 }
@@ -668,6 +677,7 @@ void free_layer(layer* l, bool)
     cuda_free(l->rolling_mean_gpu); cuda_free(l->rolling_variance_gpu);
     cuda_free(l->variance_delta_gpu); cuda_free(l->mean_delta_gpu);
     cuda_free(l->x_gpu); cuda_free(l->x_norm_gpu);
+    DkDropWinograd(l);
     cuda_free(l->weights_gpu); cuda_free(l->weight_updates_gpu);
     cuda_free((float*)l->weights_half_gpu);
     cuda_free(l->dual_weights_gpu); cuda_free(l->dual_biases_gpu);

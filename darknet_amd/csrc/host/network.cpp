@@ -29,12 +29,15 @@ int DkYoloNumDetectionsBatch(layer const* l, int b, float thresh);
 int DkGetYoloDetectionsBatch(
     layer const* l, int b, int net_w, int net_h, float thresh, Detection* dets, int* ids);
 void DkConvPrepare(layer* l);
+void DkDropWinograd(layer* l);
 
 void DkSetFusion(int on) { g_dk_fusion = on; }
 void DkSetGraph(int on) { g_dk_graph = on; }
 void DkSetAutotune(int on) { g_dk_autotune = on; }
 int g_dk_half = -1;
 void DkSetHalf(int on) { g_dk_half = on; }
+int g_dk_winograd = -1;
+void DkSetWinograd(int on) { g_dk_winograd = on; }
 extern "C" LIB_API void DkSetPullHeads(int on) { g_dk_pull_heads = on; }
 // per-network overrides (stored +1; 0 = follow the process-wide setting)
 void DkNetSetGraph(Network* net, int on) { net->opt_graph = on < 0 ? 0 : (on ? 2 : 1); }
@@ -159,6 +162,15 @@ void DkInvalidateGraph(Network* net)
   }
 }
 
+void DkDropWinograd(layer* l)
+{
+  if (!l->weights_wino_gpu)
+    return;
+  dk_conv_wino_register(l->weights_gpu, nullptr);
+  cuda_free(l->weights_wino_gpu);
+  l->weights_wino_gpu = nullptr;
+}
+
 static void autotune_convs(Network* net)
 {
   const int ncfg = dk_conv_num_configs();
@@ -202,7 +214,7 @@ static void autotune_convs(Network* net)
         std::vector<float> times(ncfg, 0.f);
         for (int c = 0; c < ncfg; ++c)
         {
-          if (!dk_conv_config_applicable(&hd, c))
+          if (!dk_conv_config_applicable(&hd, c) || (dk_conv_config_is_wino(c) && !l->weights_wino_gpu))
             continue;
           l->conv_cfg = c;
           l->forward_gpu(l, s);  // warm
@@ -405,6 +417,27 @@ void DkPlanInference(Network* net)
     if (dk_conv_half_pack_weights(&hd2, l->weights_gpu, l->weights_half_gpu, get_cuda_stream()))
       error("dk_conv_half_pack_weights failed");
   }
+  // 1d. Winograd candidates: transformed filters for every layer the kernel can take; the autotune
+  // below decides per layer, and the copies of the layers that keep another kernel are dropped again
+  {
+    const char* ew = getenv("DK_WINOGRAD");
+    const bool wino = (g_dk_winograd >= 0 ? g_dk_winograd : (ew ? atoi(ew) : 1)) != 0;
+    for (int i = 0; i < net->n; ++i)
+    {
+      layer* l = &net->layers[i];
+      if (l->type != CONVOLUTIONAL)
+        continue;
+      DkDropWinograd(l);
+      DkConvDesc wd = {l->batch, l->c, l->h, l->w, l->n, l->groups, l->size, l->stride_x, l->stride_y, l->dilation, l->pad, (int)l->activation};
+      const size_t nu = dk_conv_wino_weights_size(&wd);
+      if (!wino || !nu || l->batch_normalize || l->weights_half_gpu || l->dual_with > 0 || l->dual_slave)
+        continue;
+      l->weights_wino_gpu = cuda_make_array(nullptr, nu);
+      if (dk_conv_wino_transform_weights(&wd, l->weights_gpu, l->weights_wino_gpu, get_cuda_stream()))
+        error("dk_conv_wino_transform_weights failed");
+      dk_conv_wino_register(l->weights_gpu, l->weights_wino_gpu);
+    }
+  }
   // 2. tap tables (must exist before any stream capture)
   for (int i = 0; i < net->n; ++i)
     if (net->layers[i].type == CONVOLUTIONAL)
@@ -422,6 +455,7 @@ void DkPlanInference(Network* net)
     for (int k = 0; k < 8; ++k) { tkey ^= (unsigned long long)((v >> (8 * k)) & 0xff); tkey *= 1099511628211ULL; }
   };
   mix(net->n); mix(net->batch); mix(net->cudnn_half); mix(dk_conv_num_configs());
+  for (int i = 0; i < net->n; ++i) mix(net->layers[i].weights_wino_gpu != nullptr);
   for (int i = 0; i < net->n; ++i)
   {
     const layer* l = &net->layers[i];
@@ -466,6 +500,13 @@ void DkPlanInference(Network* net)
         for (int i = 0; i < net->n; ++i) fprintf(f, "%d\n", net->layers[i].conv_cfg);
         fclose(f);
       }
+  }
+  // transformed filters of the layers that did not choose the Winograd kernel are not needed
+  for (int i = 0; i < net->n; ++i)
+  {
+    layer* l = &net->layers[i];
+    if (l->type == CONVOLUTIONAL && l->weights_wino_gpu && !dk_conv_config_is_wino(l->conv_cfg))
+      DkDropWinograd(l);
   }
   DkInvalidateGraph(net);
   net->planned = 1;

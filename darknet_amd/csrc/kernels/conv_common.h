@@ -46,6 +46,9 @@ struct ConvArgs
   unsigned y2_bytes;
   int Mtot2, m_split;
   int nwork;         // persistent kernels: number of virtual workgroups (the grid a one-tile-per-block launch would use)
+  // Winograd F(2x2,3x3) (conv3x3_wino.hip): N counts 2x2 output tiles, tiles_w per row, tiles_hw per image
+  int tiles_w, tiles_hw;
+  double inv_tiles_w, inv_tiles_hw;
 };
 
 // exact floor(n / d) for 0 <= n < 2^31, d > 0, given inv = 1.0 / d: the double estimate is within

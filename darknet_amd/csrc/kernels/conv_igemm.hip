@@ -449,6 +449,14 @@ const char* dk_conv_dma1x1_kernel_name(int c);
 int dk_conv_dma1x1_bm(int c);
 bool dk_conv_dma1x1_applicable(const DkConvDesc* d, const float* x, const float* weights, int c);
 void dk_conv_dma1x1_launch(ConvArgs a, int c, hipStream_t st);
+// conv3x3_wino.hip: fused Winograd F(2x2,3x3) for 3x3/s1/p1 layers; numbered after the DMA configurations.
+// It needs the layer's transformed filters (dk_conv_wino_transform_weights + dk_conv_wino_register).
+int dk_conv_wino_num_configs();
+const char* dk_conv_wino_config_name(int c);
+const char* dk_conv_wino_kernel_name(int c, int variant);
+bool dk_conv_wino_applicable(const DkConvDesc* d, int c);
+const float* dk_conv_wino_lookup(const float* weights);
+int dk_conv_wino_launch(ConvArgs a, int c, hipStream_t st);
 
 namespace
 {
@@ -642,9 +650,10 @@ Plan& get_plan(const DkConvDesc* d, int K, int C, int mode = 0)
 }  // namespace
 
 // configuration index space: [0, g_ncfg) gather shapes, then the direct 3x3 shapes, then the
-// LDS-DMA 1x1 shapes
+// LDS-DMA 1x1 shapes, then the Winograd 3x3 shapes
 static int dma_base() { return g_ncfg + dk_conv_direct_num_configs(); }
-static int total_cfgs() { return dma_base() + dk_conv_dma1x1_num_configs(); }
+static int wino_base() { return dma_base() + dk_conv_dma1x1_num_configs(); }
+static int total_cfgs() { return wino_base() + dk_conv_wino_num_configs(); }
 
 extern "C" int dk_conv_force_config(int cfg)
 {
@@ -654,6 +663,8 @@ extern "C" int dk_conv_force_config(int cfg)
 
 extern "C" const char* dk_conv_config_name(int cfg)
 {
+  if (cfg >= wino_base())
+    return dk_conv_wino_config_name(cfg - wino_base());
   if (cfg >= dma_base())
     return dk_conv_dma1x1_config_name(cfg - dma_base());
   if (cfg >= g_ncfg)
@@ -667,10 +678,14 @@ bool dk_conv_config_applicable(const DkConvDesc* d, int cfg)
     return false;
   if (cfg < g_ncfg)
     return true;
+  if (cfg >= wino_base())
+    return dk_conv_wino_applicable(d, cfg - wino_base());
   if (cfg >= dma_base())
     return dk_conv_dma1x1_applicable(d, nullptr, nullptr, cfg - dma_base());
   return dk_conv_direct_applicable(d, nullptr, cfg - g_ncfg);
 }
+
+bool dk_conv_config_is_wino(int cfg) { return cfg >= wino_base() && cfg < total_cfgs(); }
 
 extern "C" int dk_conv_pick_config(const DkConvDesc* d)
 {
@@ -777,6 +792,8 @@ extern "C" __attribute__((visibility("default"))) const char* dk_conv_kernel_nam
     snprintf(buf, sizeof(buf), "%s", g_named_slots[idx - 256].c_str());
     return buf;
   }
+  if (idx >= wino_base() * 4)
+    return dk_conv_wino_kernel_name(idx / 4 - wino_base(), idx & 3);
   if (idx >= dma_base() * 4)
     return dk_conv_dma1x1_kernel_name(idx / 4 - dma_base());
   if (idx >= g_ncfg * 4)
@@ -945,7 +962,24 @@ int dk_conv_forward_cfg(const DkConvDesc* d, const float* x, const float* weight
     const int ntot = dma_base();
     if (want < 0)
       want = pick_direct(d, weights, M, a.N);
-    if (want >= dma_base() && want < total_cfgs() && dk_conv_dma1x1_applicable(d, a.x, weights, want - dma_base()) &&
+    // Winograd: only with registered transformed filters, never with a pre-activation store or a
+    // dual output (neither occurs on the inference loads that select it)
+    const float* wino_u = (want >= wino_base() && want < total_cfgs() && !activation_input && !dual &&
+                              dk_conv_wino_applicable(d, want - wino_base()))
+                              ? dk_conv_wino_lookup(weights)
+                              : nullptr;
+    if (wino_u)
+    {
+      DkProfScope ps;
+      dk_prof_begin(ps, st);
+      ConvArgs aw = a;
+      aw.w = wino_u;
+      const int variant = dk_conv_wino_launch(aw, want - wino_base(), st);
+      CHECK_HIP(hipPeekAtLastError());
+      dk_prof_end(ps, st, want * 4 + variant, 2.0 * (double)M * K * (double)a.N / 1e9);
+      continue;
+    }
+    if (want >= dma_base() && want < wino_base() && dk_conv_dma1x1_applicable(d, a.x, weights, want - dma_base()) &&
         !(dual && dual->m_split % dk_conv_dma1x1_bm(want - dma_base())))
     {
       ProfRec pr;

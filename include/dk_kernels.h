@@ -104,6 +104,13 @@ DK_API int dk_upsample_forward(const float* in, int w, int h, int c, int batch,
  * (fp32 -> fp16 round to nearest even).  The network plan packs once per layer at load. */
 DK_API size_t dk_conv_half_direct_weights_size(const DkConvDesc* d);
 DK_API int dk_conv_half_pack_weights(const DkConvDesc* d, const float* weights, void* packed, void* stream);
+/* Winograd F(2x2,3x3) path of dk_conv_forward (3x3/s1/p1, groups 1, c % 8 == 0, n % 64 == 0): the filters are
+ * transformed once (U = G g G^T, dk_conv_wino_weights_size floats) and registered under the layer's weights
+ * pointer; dk_conv_forward_cfg with the Winograd configuration index then finds them.  Re-transform after
+ * every change of the weights; register U = NULL before freeing. */
+DK_API size_t dk_conv_wino_weights_size(const DkConvDesc* d);
+DK_API int dk_conv_wino_transform_weights(const DkConvDesc* d, const float* weights, float* U, void* stream);
+DK_API void dk_conv_wino_register(const float* weights, const float* U);
 /* y = act(conv(fp16(x), packed fp16 weights) + bias) (+ residual), fp32 accumulate */
 DK_API int dk_conv_forward_half_packed(const DkConvDesc* d, const float* x, const void* packed_weights,
     const float* biases, float* y, const float* residual, void* stream);

@@ -224,6 +224,7 @@ struct layer
   float *dual_weights_gpu, *dual_biases_gpu;
   struct layer* dual_peer; /* the other conv of a dual launch (master <-> slave), or NULL */
   void* weights_half_gpu; /* fp16 weights packed for conv3x3_direct_f16 (inference plan with cudnn_half), or NULL */
+  float* weights_wino_gpu; /* filters transformed for conv3x3_wino_f32 (inference plan, DkSetWinograd), or NULL */
   int delta_in_arena;    /* delta_gpu points into net->delta_arena_gpu (not freed per layer) */
   int buffers_aliased;   /* [dropout]: output_gpu / delta_gpu are the previous layer's (not freed here) */
   float* out_view;       /* producer: where the output really goes (a channel slice), or NULL */
@@ -479,6 +480,10 @@ LIB_API void DkSetAutotune(int on);
 /* fp16-operand convolutions for the layers the reference's CUDNN_HALF rule admits
  * (sets net->cudnn_half at the next load; also env DK_HALF=1) */
 LIB_API void DkSetHalf(int on);
+/* 1 (default; env DK_WINOGRAD): the inference plan may run 3x3/s1 layers with the fused Winograd F(2x2,3x3)
+ * kernel where the per-layer autotune measures it faster (results within the fp32 tolerance, not bitwise
+ * equal to the direct kernels); 0: only the k-ascending implicit-GEMM kernels. */
+LIB_API void DkSetWinograd(int on);
 
 /* Flat helpers for FFI callers (ctypes, tests, bench.py) */
 LIB_API Network* DkNetworkCreate(void);            /* calloc'ed Network */

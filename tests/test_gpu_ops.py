@@ -324,3 +324,54 @@ def test_conv_dma1x1_vs_oracle(gpu, case):
     for cfg in dma:
         assert out[cfg * 4 * 3] == 2, "config %s did not launch" % names[cfg]
     L.dk_conv_force_config(-1)
+
+
+WINO_CASES = [
+    # batch, c, h, w, n, act, residual
+    (2, 64, 38, 38, 64, "MISH", True),      # even map, full tiles
+    (3, 32, 19, 19, 128, "LEAKY", False),   # odd map: ragged tile row / column, b32 store path
+    (1, 8, 13, 13, 64, "LINEAR", True),     # one stage (C = 8), odd, residual on the b32 path
+    (2, 128, 76, 76, 128, "MISH", True),    # yolov4's most frequent shape
+    (1, 512, 19, 19, 512, "LEAKY", False),  # long K (64 stages), partitioned launch (U > 3 MB)
+    (5, 16, 6, 10, 64, "LOGISTIC", False),  # generic activation path, tiles straddling images
+    (1, 24, 2, 2, 192, "RELU", False),      # one tile per image
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_conv_winograd_vs_oracle(gpu, case):
+    """Fused Winograd F(2x2,3x3) kernel (conv3x3_wino.hip) vs the CPU oracle of the reference's im2col+GEMM
+    (convolutional_layer.cpp:1128-1305).  Not bitwise equal to the direct kernels by construction; bound =
+    the fp32 tolerance of util.py, and the measured distance is printed next to the direct kernel's."""
+    batch, c, h, w, n, actname, with_res = case
+    act = getattr(O, actname)
+    rng = np.random.default_rng(hash(case) & 0xFFFF)
+    x = rng.uniform(-1, 1, (batch, c, h, w)).astype(np.float32)
+    wt = (rng.uniform(-1, 1, (n, c, 3, 3)) * np.sqrt(2.0 / (9 * c))).astype(np.float32)
+    bias = rng.uniform(-.5, .5, n).astype(np.float32)
+    res = rng.uniform(-1, 1, (batch, n, h, w)).astype(np.float32) if with_res else None
+    ref, _ = orc_conv(x, wt, bias, batch, c, h, w, n, 3, 1, 1, act)
+    if with_res:
+        ref = ref + res
+    L = gpu.lib()
+    ncfg = L.dk_conv_force_config(-1)
+    names = [L.dk_conv_config_name(i).decode() for i in range(ncfg)]
+    wino = [i for i, nm in enumerate(names) if nm.startswith("wino")]
+    assert wino
+    y_direct = gpu.conv_forward(x, wt, bias, batch, c, h, w, n, 3, 1, 1, act, residual=res)
+    L.dk_profile_enable(1)
+    try:
+        for cfg in wino:
+            L.dk_conv_force_config(cfg)
+            y = gpu.conv_forward(x, wt, bias, batch, c, h, w, n, 3, 1, 1, act, residual=res, wino=True)
+            rms = float(np.sqrt(np.mean(ref.astype(np.float64) ** 2)))
+            print("winograd %s %s: max|d|/rms %.3g (direct kernel: %.3g)" % (names[cfg], case,
+                np.abs(y - ref).max() / rms, np.abs(y_direct - ref).max() / rms))
+            util.assert_close(y, ref, "conv %s %s" % (names[cfg], case))
+    finally:
+        L.dk_conv_force_config(-1)
+    out = (C.c_double * (3 * 256))()
+    L.dk_profile_read(out, 256)
+    L.dk_profile_enable(0)
+    for cfg in wino:
+        assert out[cfg * 4 * 3] + out[(cfg * 4 + 1) * 3] == 1, "config %s did not launch" % names[cfg]

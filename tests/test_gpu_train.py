@@ -568,24 +568,36 @@ def test_c4_yolov4_608_b8_train_step_vs_reference_golden(gpu, tmp_path):
     #      size: ITS outputs sit up to ref_vs_f64stats_max_over_rms (4.9e-3 x rms at layer 0, growing to
     #      0.4 x rms near the heads as 107 batch-normalised layers amplify it) away from (a) -- the
     #      fixture stores that distance per layer, and it bounds the HIP-vs-reference distance here.
-    worst_a = worst_b = 0.0
+    # Tolerance vs (a): util.TRAIN_ATOL_RMS (3e-4 x rms, measured on yolov4-tiny's 21 batch-normalised layers)
+    # up to layer 133.  From layer 134 on (the 19x19 neck/head: 2888 samples per channel at b=8) this random-init
+    # network amplifies ANY upstream perturbation 30-100x -- the fixture shows it on the reference itself,
+    # whose distance from (a) jumps from 3.4e-3 x rms (layer 130) to 0.09-0.43 x rms (layers 134-160).  The
+    # HIP path's fp32 summation-order differences are amplified alike (measured on MI355X: 4.1e-4 x rms at
+    # layer 134, 1.03e-3 at layer 146), so there the bound is "100x closer to (a) than the reference is".
+    worst_a = worst_b = worst_ratio = 0.0
     shift = g["ref_vs_f64stats_max_over_rms"]
+    bad = []
     for row, row64 in zip(g["fwd_summaries"], g["fwd_summaries_f64stats"]):
         i = int(row[0])
         a = net.output(i).ravel()
         idx = np.linspace(0, a.size - 1, 64).astype(np.int64)
         got = a[idx].astype(np.float64)
         rms = np.sqrt(row64[2] / a.size)
+        atol = max(util.TRAIN_ATOL_RMS, 1e-2 * float(shift[i]))
         d64 = np.abs(got - row64[3:])
-        lim64 = util.REL * np.abs(row64[3:]) + util.TRAIN_ATOL_RMS * rms
-        assert np.all(d64 <= lim64), "train forward layer %d vs the fp64-statistics oracle: samples off by x%.3g" % (
-            i, float((d64 / np.maximum(lim64, 1e-300)).max()))
+        lim64 = util.REL * np.abs(row64[3:]) + atol * rms
         dref = np.abs(got - row[3:])
-        limref = util.REL * np.abs(row[3:]) + (util.TRAIN_ATOL_RMS + 1.5 * shift[i]) * rms
-        assert np.all(dref <= limref), "train forward layer %d vs the reference: samples off by x%.3g" % (
-            i, float((dref / np.maximum(limref, 1e-300)).max()))
+        limref = util.REL * np.abs(row[3:]) + (atol + 1.5 * shift[i]) * rms
+        r64 = float((d64 / np.maximum(lim64, 1e-300)).max())
+        rref = float((dref / np.maximum(limref, 1e-300)).max())
+        if r64 > 1 or rref > 1:
+            bad.append((i, r64, rref))
         if rms > 0:
             worst_a, worst_b = max(worst_a, float(d64.max() / rms)), max(worst_b, float(dref.max() / rms))
+            if shift[i] > 0:
+                worst_ratio = max(worst_ratio, float(d64.max() / rms / shift[i]))
+    print("C4 train forward: HIP distance / reference distance from the fp64-statistics oracle, worst layer: %.3g" % worst_ratio)
+    assert not bad, "train forward layers off (layer, x tolerance vs fp64-statistics oracle, x tolerance vs reference): %s" % bad[:8]
     print("C4 train forward, 162 layers: worst |d|/rms %.3g vs the fp64-statistics oracle, %.3g vs the reference "
           "(whose own distance from that oracle reaches %.3g)" % (worst_a, worst_b, float(shift.max())))
     for i in range(net.n):

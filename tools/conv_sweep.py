@@ -60,6 +60,12 @@ def main():
         bs = dk.DeviceArray(rng.uniform(-1, 1, n).astype(np.float32))
         L.dk_conv_force_config(-1)
         heur = L.dk_conv_pick_config(C.byref(d))
+        du = None
+        nu = L.dk_conv_wino_weights_size(C.byref(d))
+        if nu:   # Winograd candidate: transformed filters registered under the weights pointer
+            du = dk.DeviceArray(n=nu)
+            L.dk_conv_wino_transform_weights(C.byref(d), wt.ptr, du.ptr, None)
+            L.dk_conv_wino_register(wt.ptr, du.ptr)
         times = []
         for cfgi in range(ncfg):
             L.dk_conv_force_config(cfgi)
@@ -86,6 +92,9 @@ def main():
         print("L%-4d x%-2d c%-4d %3dx%-3d n%-4d k%d s%d  GF %7.2f | " % (idxs[0], cnt, c, h, w, n, size, stride, gf) +
               " ".join("%6.3f" % t for t in times) + " | best %d (%5.1f TF) heur %d (%5.1f TF)" %
               (best, gf / times[best], heur, gf / times[heur]), flush=True)
+        if du is not None:
+            L.dk_conv_wino_register(wt.ptr, None)
+            du.free()
         wt.free(); bs.free()
     L.dk_conv_force_config(-1)
     print("configs:", names)
