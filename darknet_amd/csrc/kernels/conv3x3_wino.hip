@@ -14,19 +14,24 @@
 //
 // Decomposition: the 16 positions xi = (i, j) of the 4x4 transformed tile are 16 independent GEMMs
 //     Mx[xi][m][t] = sum_c U[xi][m][c] * V[xi][c][t]      m = filter, t = output tile (b, ty, tx)
-// A workgroup (4 waves) owns 64 filters x 64 tiles for ALL 16 positions; wave (wm, wn) owns a
-// 32 x 32 sub-block, 16 accumulators of v_mfma_f32_32x32x2_f32 = 256 registers: the C/D layout puts
-// the 16 positions of one (m, t) in the SAME lane and register index, so the output transform
-// A^T Mx A is pure per-lane register arithmetic -- no exchange through LDS.
+// A workgroup (4 waves) owns 64 filters x 64 consecutive tiles for ALL 16 positions; wave (wm, wn)
+// owns a 32 x 32 sub-block, 16 accumulators of v_mfma_f32_32x32x2_f32 = 256 registers: the C/D
+// layout puts the 16 positions of one (m, t) in the SAME lane and register index, so the output
+// transform A^T Mx A is pure per-lane register arithmetic -- no exchange through LDS.
 //
-// K loop, 8 input channels per stage, LDS double-buffered, one barrier per stage (64 MFMAs/wave):
+// K loop, 8 input channels per stage (64 MFMAs per wave), two barriers per stage:
 //   * U (filters transformed once per layer by dk_conv_wino_transform_weights) lies in HBM as one
 //     contiguous 32 KB slab per (filter tile, stage) in exactly the LDS image, so staging is a
 //     straight 16-byte copy;
-//   * V is produced in the kernel: a thread owns (channel, tile) pairs, fetches the 4x4 input
-//     patch (padding and ragged edges through the buffer descriptor's range check: masked
-//     elements get an out-of-range offset and read as 0), applies B^T d B (32 additions) and
-//     writes the 16 positions to LDS;
+//   * the input rows the strip of 64 tiles touches are staged ONCE per stage as a raw patch in
+//     LDS with coalesced 16 / 8 / 4-byte loads (template VW = 4 / 2 / 1 by the row alignment W
+//     allows): per channel, the 4 input rows of every tile row of the strip, pitch Pw.  (The first
+//     version gathered each tile's 4x4 patch straight from global memory with 32 scalar loads per
+//     thread and stage: the address path of those uncoalesced loads, not their bytes, cost 30 % of
+//     the kernel -- ablation builds)
+//   * V = B^T d B is produced from the raw patch by VALU work that is INTERLEAVED with the MFMAs
+//     of the previous stage (one wave per SIMD: nothing else would overlap them), into the other
+//     half of a double-buffered V image;
 //   * operands are read back as ds_read_b128: lanes 0-31 get channels 0-3 of the stage, lanes
 //     32-63 channels 4-7, so one read feeds four MFMAs (k pairs (j, 4+j)); the LDS image
 //     [xi][sub-block][half][32 rows][4 floats] makes both the b128 reads and the transform's
@@ -42,6 +47,12 @@
 #include "dark_hip.h"
 #include "dk_device_math.h"
 #include "dk_internal.h"
+
+// diagnostic ablation builds (tools/build_ablate_wino.sh; results are garbage by construction):
+// bit 0 no input loads, 1 no filter loads, 2 no input transform / V writes, 3 no U writes, 4 no raw-patch writes
+#ifndef DK_WABL
+#define DK_WABL 0
+#endif
 
 namespace
 {
@@ -63,12 +74,18 @@ __host__ __device__ __forceinline__ int img_off(int xi, int sub, int r32, int c8
   return xi * 512 + sub * 256 + (c8 >> 2) * 128 + r32 * 4 + (c8 & 3);
 }
 
-template <bool PAIR>
+// loads per thread and stage of the raw patch the kernel is compiled for (host: wino_geometry)
+constexpr int wino_kmax(int vw) { return vw == 4 ? 15 : (vw == 2 ? 20 : 28); }
+
+template <int VW, bool PAIR>
 __global__ void __launch_bounds__(256) conv3x3_wino_f32(const ConvArgs p)
 {
+  constexpr int KMAX = wino_kmax(VW);
+  constexpr int SH = (VW & 1) ? 0 : 1;   // raw rows start one float in when VW is even: tile columns stay 8-byte aligned
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* const Us = lds;                 // [2][W_STAGE]
-  float* const Vs = lds + 2 * W_STAGE;   // [2][W_STAGE]
+  float* const Us = lds;                 // [W_STAGE]      filters of the stage being multiplied
+  float* const Vs = lds + W_STAGE;       // [2][W_STAGE]   transformed input, double-buffered
+  float* const Rs = lds + 3 * W_STAGE;   // raw input rows of the NEXT stage: [8 ch][RS rows][Pw]
 
   int g, tile_m, tile_n;
   if (!conv_block_tile(p, g, tile_m, tile_n))
@@ -80,42 +97,62 @@ __global__ void __launch_bounds__(256) conv3x3_wino_f32(const ConvArgs p)
   const int wm = wave & 1, wn = wave >> 1;
   const int m0 = tile_m * WBM, n0 = tile_n * WBN;
   const int nst = p.C / WCK;
-  const int TW = p.tiles_w, THW = p.tiles_hw;
+  const int TW = p.tiles_w, THW = p.tiles_hw, TH = p.wino_th;
+  const int GP = p.wino_gp, RS = p.wino_rs, NK = p.wino_nk;
+  const int Pw = VW * GP;
 
   __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
 
+  // ---- geometry of the strip: tile rows R0 .. Rlast (R = b * TH + ty), first tile column tx0 ----
+  const int R0 = fdiv(n0, TW, p.inv_tiles_w);
+  const int tx0 = n0 - R0 * TW;
+  const int nlast = (n0 + WBN - 1 < p.N) ? n0 + WBN - 1 : p.N - 1;
+  const int Rlast = fdiv(nlast, TW, p.inv_tiles_w);
+  const bool wide = TW > WBN;   // then the strip spans at most two tile rows and row 0 starts at tx0
+  // first loaded column group of local tile row r: floor((2 * txs - 1) / VW), txs = first tile column staged
+  auto g0_of = [&](int r) { const int txs = (wide && r == 0) ? tx0 : 0; return (2 * txs - 1 + VW) / VW - 1; };
+
+  // ---- raw patch loads: element e = tid + 256 * k is column group g of row (c, r, i) ------------
+  unsigned xoff[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k)
+  {
+    const int e = tid + 256 * k;
+    const int c = fdiv(e, RS * GP, p.inv_wino_rsg);
+    const int rem = e - c * RS * GP;
+    const int rowi = fdiv(rem, GP, p.inv_wino_gp);
+    const int gg = rem - rowi * GP;
+    const int r = rowi >> 2, i = rowi & 3;
+    const int R = R0 + r;
+    const int b = fdiv(R, TH, p.inv_wino_th);
+    const int ty = R - b * TH;
+    const int iy = 2 * ty - 1 + i;
+    const int col0 = VW * (g0_of(r) + gg);
+    const bool ok = k < NK && c < WCK && R <= Rlast && iy >= 0 && iy < p.H && col0 >= 0 && col0 < p.W;
+    xoff[k] = ok ? (unsigned)(((b * p.Ctot + c) * p.H + iy) * p.W + col0) * 4u : OOB;
+  }
+
   // ---- input-transform ownership: two (channel, tile) pairs per thread ------------------------
   // lane -> channel (lane & 3) + 4 * (lane >> 5), tile ((lane >> 2) & 7) of an 8-tile group;
   // wave w, pass q -> tile group 2w + q.  (The 32 lanes of a half-wave then write 32 distinct
-  // LDS banks for every position.)
+  // LDS banks for every position, and read 64 distinct banks of the raw patch with ds_read_b64
+  // when the host could make the channel stride RS * Pw = 16 mod 32 floats.)
   const int c8 = (lane & 3) + 4 * lh;
-  unsigned xoff[2][16];
-  int vdst[2];
+  int rsrc[2], vdst[2];
 #pragma unroll
   for (int q = 0; q < 2; ++q)
   {
     const int tl = (wave * 2 + q) * 8 + ((lane >> 2) & 7);
-    const int n = n0 + tl;
-    const bool nv = n < p.N;
-    const int nn = nv ? n : 0;
-    const int b = fdiv(nn, THW, p.inv_tiles_hw);
-    const int r = nn - b * THW;
-    const int ty = fdiv(r, TW, p.inv_tiles_w);
-    const int tx = r - ty * TW;
-    const int iy0 = 2 * ty - 1, ix0 = 2 * tx - 1;
-    const int base = ((b * p.Ctot + c8) * p.H + iy0) * p.W + ix0;
-#pragma unroll
-    for (int e = 0; e < 16; ++e)
-    {
-      const int iy = iy0 + (e >> 2), ix = ix0 + (e & 3);
-      const bool ok = nv && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-      xoff[q][e] = ok ? (unsigned)(base + (e >> 2) * p.W + (e & 3)) * 4u : OOB;
-    }
+    const int n = (n0 + tl < p.N) ? n0 + tl : nlast;
+    const int R = fdiv(n, TW, p.inv_tiles_w);
+    const int tx = n - R * TW;
+    const int r = R - R0;
+    rsrc[q] = (c8 * RS + 4 * r) * Pw + 2 * tx - 1 - VW * g0_of(r) + SH;
     vdst[q] = img_off(0, tl >> 5, tl & 31, c8);
   }
   const unsigned stage_x_bytes = (unsigned)(WCK * p.H * p.W) * 4u;
-  const unsigned ubase = (unsigned)(tile_m * nst) * (unsigned)(W_STAGE * 4);
+  const unsigned ubase = (unsigned)(tile_m * nst) * (unsigned)(W_STAGE * 4) + (unsigned)tid * 16u;
 
   f32x16 acc[16];
 #pragma unroll
@@ -123,77 +160,174 @@ __global__ void __launch_bounds__(256) conv3x3_wino_f32(const ConvArgs p)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-  float raw[2][16];
+  float raw[KMAX][VW];
   float4 ureg[8];
-  auto load_stage = [&](int t) {
+  auto load_raw = [&](int t) {
     const unsigned xo = (unsigned)t * stage_x_bytes;
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int k = 0; k < KMAX; ++k)
+    {
+      if (k < NK)
+      {
+        if (DK_WABL & 1)
+        {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) raw[q][e] = ld_buf(xr, xoff[q][e] + xo);
-    const unsigned uo = ubase + (unsigned)t * (unsigned)(W_STAGE * 4) + (unsigned)tid * 16u;
+          for (int j = 0; j < VW; ++j) raw[k][j] = 1.f;
+        }
+        else if constexpr (VW == 4)
+        {
+          const float4 v = ld_buf4(xr, xoff[k] + xo);
+          raw[k][0] = v.x; raw[k][1] = v.y; raw[k][2] = v.z; raw[k][3] = v.w;
+        }
+        else if constexpr (VW == 2)
+        {
+          const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(xr, (int)(xoff[k] + xo), 0, 0);
+          raw[k][0] = __uint_as_float(v.x); raw[k][1] = __uint_as_float(v.y);
+        }
+        else
+          raw[k][0] = ld_buf(xr, xoff[k] + xo);
+      }
+    }
+  };
+  auto write_raw = [&]() {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ureg[j] = ld_buf4(ur, uo + (unsigned)j * 4096u);
+    for (int k = 0; k < KMAX; ++k)
+    {
+      if (k < NK && !(DK_WABL & 16))
+      {
+        float* const dst = Rs + VW * (tid + 256 * k) + SH;
+#pragma unroll
+        for (int j = 0; j < VW; ++j) dst[j] = raw[k][j];
+      }
+    }
+  };
+  auto load_u = [&](int t) {
+    const unsigned uo = ubase + (unsigned)t * (unsigned)(W_STAGE * 4);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ureg[j] = (DK_WABL & 2) ? make_float4(1.f, 1.f, 1.f, 1.f) : ld_buf4(ur, uo + (unsigned)j * 4096u);
+  };
+  auto write_u = [&]() {
+#pragma unroll
+    for (int j = 0; j < ((DK_WABL & 8) ? 0 : 8); ++j) ((float4*)Us)[tid + j * 256] = ureg[j];
   };
 
-  load_stage(0);
+  // V = B^T d B of this thread's two patches, cut into 16 slices (pair q = s / 8): slices 0-3 of a
+  // pair request the four patch rows, slice 4 applies (d B) to the rows, slices 4-7 finish one
+  // row of B^T (..) each and write its four positions.
+  float dd[4][4], ww[4][4];
+  auto tslice = [&](auto sc, float* Vnext) {
+    constexpr int sidx = decltype(sc)::value;
+    constexpr int q = sidx >> 3, part = sidx & 7;
+    if (DK_WABL & 4)
+      return;
+    if constexpr (part < 4)
+    {
+      const float2* const src = (const float2*)(Rs + rsrc[q] + part * Pw);
+      const float2 lo = src[0], hi = src[1];
+      dd[part][0] = lo.x; dd[part][1] = lo.y; dd[part][2] = hi.x; dd[part][3] = hi.y;
+    }
+    else
+    {
+      if constexpr (part == 4)
+      {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+          ww[i][0] = dd[i][0] - dd[i][2];
+          ww[i][1] = dd[i][1] + dd[i][2];
+          ww[i][2] = dd[i][2] - dd[i][1];
+          ww[i][3] = dd[i][1] - dd[i][3];
+        }
+      }
+      constexpr int i = part - 4;
+      float* const dst = Vnext + vdst[q] + i * 4 * 512;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+      {
+        const float v = i == 0 ? ww[0][j] - ww[2][j] : i == 1 ? ww[1][j] + ww[2][j] : i == 2 ? ww[2][j] - ww[1][j] : ww[1][j] - ww[3][j];
+        dst[j * 512] = v;
+      }
+    }
+  };
+  auto tslices4 = [&](auto gc, float* Vnext) {   // the four slices that accompany MFMA group gc
+    constexpr int s0 = decltype(gc)::value * 4;
+    tslice(std::integral_constant<int, s0>(), Vnext);
+    tslice(std::integral_constant<int, s0 + 1>(), Vnext);
+    tslice(std::integral_constant<int, s0 + 2>(), Vnext);
+    tslice(std::integral_constant<int, s0 + 3>(), Vnext);
+  };
+
+  // ---- prologue: raw(0) -> LDS, V(0) ----------------------------------------------------------
+  load_raw(0);
+  write_raw();
+  __syncthreads();
+  if (nst > 1)
+    load_raw(1);
+  load_u(0);
+  tslices4(std::integral_constant<int, 0>(), Vs);
+  tslices4(std::integral_constant<int, 1>(), Vs);
+  tslices4(std::integral_constant<int, 2>(), Vs);
+  tslices4(std::integral_constant<int, 3>(), Vs);
+
+  const float4* const Ua = (const float4*)Us + wm * 64 + lh * 32 + l31;
   for (int t = 0; t < nst; ++t)
   {
-    float* const Ub = Us + (t & 1) * W_STAGE;
-    float* const Vb = Vs + (t & 1) * W_STAGE;
-    // ---- V = B^T d B of this thread's two patches -> LDS -----------------------------------
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-    {
-      float tm[4][4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-      {
-        const float d0 = raw[q][s], d1 = raw[q][4 + s], d2 = raw[q][8 + s], d3 = raw[q][12 + s];
-        tm[0][s] = d0 - d2;
-        tm[1][s] = d1 + d2;
-        tm[2][s] = d2 - d1;
-        tm[3][s] = d1 - d3;
-      }
-      float* const dst = Vb + vdst[q];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-      {
-        dst[(i * 4 + 0) * 512] = tm[i][0] - tm[i][2];
-        dst[(i * 4 + 1) * 512] = tm[i][1] + tm[i][2];
-        dst[(i * 4 + 2) * 512] = tm[i][2] - tm[i][1];
-        dst[(i * 4 + 3) * 512] = tm[i][1] - tm[i][3];
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ((float4*)Ub)[tid + j * 256] = ureg[j];
+    // A: V(t) complete, every read of raw(t) and of U(t-1) done
     __syncthreads();
     if (t + 1 < nst)
-      load_stage(t + 1);
-    // ---- 16 positions x 4 k-pairs ----------------------------------------------------------
-    const float4* const Ua = (const float4*)Ub + wm * 64 + lh * 32 + l31;
-    const float4* const Va = (const float4*)Vb + wn * 64 + lh * 32 + l31;
-    // fragments of position xi + 1 are requested before the MFMAs of position xi are issued: with one
-    // wave per SIMD nothing else hides the LDS latency
-    float4 fa[2], fb[2];
-    fa[0] = Ua[0];
-    fb[0] = Va[0];
+      write_raw();   // raw(t+1)
+    write_u();       // U(t)
+    __syncthreads();
+    if (t + 2 < nst)
+      load_raw(t + 2);
+    if (t + 1 < nst)
+      load_u(t + 1);
+    const float4* const Va = (const float4*)(Vs + (t & 1) * W_STAGE) + wn * 64 + lh * 32 + l31;
+    float* const Vnext = Vs + ((t + 1) & 1) * W_STAGE;
+    // ---- 16 positions x 4 k-pairs, four positions at a time with their MFMAs interleaved; the
+    // fragments of the next group are requested before the MFMAs of the current one are issued,
+    // and between the four MFMA rounds of a group sits one slice of the NEXT stage's input
+    // transform (after the last stage it works on stale rows into the unused V half: harmless).
+    float4 fa[2][4], fb[2][4];
 #pragma unroll
-    for (int xi = 0; xi < 16; ++xi)
+    for (int u = 0; u < 4; ++u)
     {
-      if (xi + 1 < 16)
+      fa[0][u] = Ua[u * 128];
+      fb[0][u] = Va[u * 128];
+    }
+    auto group = [&](auto gc) {
+      constexpr int grp = decltype(gc)::value;
+      if constexpr (grp + 1 < 4)
       {
-        fa[(xi + 1) & 1] = Ua[(xi + 1) * 128];
-        fb[(xi + 1) & 1] = Va[(xi + 1) * 128];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+        {
+          fa[(grp + 1) & 1][u] = Ua[((grp + 1) * 4 + u) * 128];
+          fb[(grp + 1) & 1][u] = Va[((grp + 1) * 4 + u) * 128];
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
-      const float4 a = fa[xi & 1], b = fb[xi & 1];
-      acc[xi] = mfma2(a.x, b.x, acc[xi]);
-      acc[xi] = mfma2(a.y, b.y, acc[xi]);
-      acc[xi] = mfma2(a.z, b.z, acc[xi]);
-      acc[xi] = mfma2(a.w, b.w, acc[xi]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[grp * 4 + u] = mfma2(fa[grp & 1][u].x, fb[grp & 1][u].x, acc[grp * 4 + u]);
+      tslice(std::integral_constant<int, grp * 4 + 0>(), Vnext);
       __builtin_amdgcn_sched_barrier(0);
-    }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[grp * 4 + u] = mfma2(fa[grp & 1][u].y, fb[grp & 1][u].y, acc[grp * 4 + u]);
+      tslice(std::integral_constant<int, grp * 4 + 1>(), Vnext);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[grp * 4 + u] = mfma2(fa[grp & 1][u].z, fb[grp & 1][u].z, acc[grp * 4 + u]);
+      tslice(std::integral_constant<int, grp * 4 + 2>(), Vnext);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[grp * 4 + u] = mfma2(fa[grp & 1][u].w, fb[grp & 1][u].w, acc[grp * 4 + u]);
+      tslice(std::integral_constant<int, grp * 4 + 3>(), Vnext);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    group(std::integral_constant<int, 0>());
+    group(std::integral_constant<int, 1>());
+    group(std::integral_constant<int, 2>());
+    group(std::integral_constant<int, 3>());
   }
 
   // ---- output transform A^T Mx A, bias, activation (+ residual), store ----------------------
@@ -336,15 +470,69 @@ std::mutex g_reg_mu;
 std::unordered_map<const float*, const float*> g_reg;  // layer weights (device) -> transformed filters
 }  // namespace
 
+// Raw-patch geometry of a launch (see the kernel): vector width of the row loads, column groups
+// per row (gp), rows per channel incl. bank padding (rs), loads per thread and stage (nk).
+struct WinoGeo
+{
+  int vw, gp, rs, nk;
+};
+
+bool wino_geometry(int TW, int vw, WinoGeo& o)
+{
+  const int nr = 62 / TW + 2;                  // tile rows a strip of 64 consecutive tiles can touch
+  const int nw = TW < WBN ? TW : WBN;          // tile columns staged per tile row
+  int gp = 2 * nw / vw + 2;
+  if (vw == 1 && (gp & 1))
+    ++gp;                                      // even pitch: ds_read_b64 of the tile columns
+  const int rows = 4 * nr;
+  for (int pass = 0; pass < 2; ++pass)
+  {
+    int rs = rows;
+    if (pass == 0)
+    {
+      // channel stride = 16 mod 32 floats: the four channels of a half-wave read disjoint banks
+      rs = -1;
+      for (int cand = rows; cand <= rows + 8; ++cand)
+        if ((cand * vw * gp) % 32 == 16)
+        {
+          rs = cand;
+          break;
+        }
+      if (rs < 0)
+        continue;
+    }
+    const int nk = (WCK * rs * gp + 255) / 256;
+    if (nk <= wino_kmax(vw))
+    {
+      o.vw = vw; o.gp = gp; o.rs = rs; o.nk = nk;
+      return true;
+    }
+  }
+  return false;
+}
+
+// widest row vector the layer's width admits that also fits the compiled load count
+bool wino_pick(int W, int TW, bool aligned16, bool aligned8, WinoGeo& o)
+{
+  if (W % 4 == 0 && aligned16 && wino_geometry(TW, 4, o))
+    return true;
+  if (W % 2 == 0 && aligned8 && wino_geometry(TW, 2, o))
+    return true;
+  return wino_geometry(TW, 1, o);
+}
+
 int dk_conv_wino_num_configs() { return 1; }
 const char* dk_conv_wino_config_name(int c) { return c == 0 ? "wino_64x64" : nullptr; }
 const char* dk_conv_wino_kernel_name(int c, int variant)
 {
-  if (c != 0)
-    return nullptr;
-  return variant ? "conv3x3_wino_f32<true>" : "conv3x3_wino_f32<false>";
+  static const char* names[3] = {"conv3x3_wino_f32<4, true>", "conv3x3_wino_f32<2, true>", "conv3x3_wino_f32<1, false>"};
+  return (c == 0 && variant >= 0 && variant < 3) ? names[variant] : nullptr;
 }
-bool dk_conv_wino_applicable(const DkConvDesc* d, int c) { return c == 0 && shape_ok(d); }
+bool dk_conv_wino_applicable(const DkConvDesc* d, int c)
+{
+  WinoGeo o;
+  return c == 0 && shape_ok(d) && wino_pick(d->w, (d->w + 1) / 2, true, true, o);
+}
 
 const float* dk_conv_wino_lookup(const float* weights)
 {
@@ -353,29 +541,44 @@ const float* dk_conv_wino_lookup(const float* weights)
   return it == g_reg.end() ? nullptr : it->second;
 }
 
-// Launches one batch chunk; a.w must already point at the transformed filters.  Returns the variant.
+// Launches one batch chunk; a.w must already point at the transformed filters.  Returns the variant
+// (0: 16-byte row loads, 1: 8-byte, 2: 4-byte), or -1 when the geometry does not fit (caller falls back).
 int dk_conv_wino_launch(ConvArgs a, int c, hipStream_t st)
 {
   (void)c;
   const int TH = (a.OH + 1) / 2, TW = (a.OW + 1) / 2;
   const int nb = a.N / a.OHW;
+  const bool pair = (a.OW % 2 == 0) && (((uintptr_t)a.y & 7) == 0) && (!a.residual || ((uintptr_t)a.residual & 7) == 0);
+  WinoGeo o;
+  const bool a16 = pair && ((uintptr_t)a.x & 15) == 0, a8 = pair && ((uintptr_t)a.x & 7) == 0;
+  if (!wino_pick(a.W, TW, a16, a8, o))
+    return -1;
   a.tiles_w = TW;
   a.tiles_hw = TH * TW;
   a.inv_tiles_w = 1.0 / TW;
   a.inv_tiles_hw = 1.0 / (TH * TW);
+  a.wino_th = TH;
+  a.wino_gp = o.gp;
+  a.wino_rs = o.rs;
+  a.wino_nk = o.nk;
+  a.inv_wino_th = 1.0 / TH;
+  a.inv_wino_gp = 1.0 / o.gp;
+  a.inv_wino_rsg = 1.0 / (o.rs * o.gp);
   a.N = nb * TH * TW;
   a.tiles_m = a.M / WBM;
   a.tiles_n = (a.N + WBN - 1) / WBN;
   a.groups = 1;
+  const bool drop_w = a.w_bytes == 0;   // DK_DEBUG_DROP bit 2 (timing diagnostics): zero-record descriptor
   a.w_bytes = (unsigned)((size_t)16 * a.M * a.C * sizeof(float));
   conv_args_finish(a);
   const long long nblk = conv_pick_partition(a, (size_t)a.w_bytes, WBM);
-  const int bytes = 4 * W_STAGE * (int)sizeof(float);
-  const bool pair = (a.OW % 2 == 0) && (((uintptr_t)a.y & 7) == 0) && (!a.residual || ((uintptr_t)a.residual & 7) == 0);
-  auto k = pair ? conv3x3_wino_f32<true> : conv3x3_wino_f32<false>;
+  if (drop_w)
+    a.w_bytes = 0;
+  const int bytes = (3 * W_STAGE + o.nk * 256 * o.vw + 8) * (int)sizeof(float);
+  void (*k)(const ConvArgs) = o.vw == 4 ? conv3x3_wino_f32<4, true> : (o.vw == 2 ? conv3x3_wino_f32<2, true> : conv3x3_wino_f32<1, false>);
   dk_set_max_dynamic_lds((const void*)k, bytes);
   hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), bytes, st, a);
-  return pair ? 1 : 0;
+  return o.vw == 4 ? 0 : (o.vw == 2 ? 1 : 2);
 }
 
 extern "C" size_t dk_conv_wino_weights_size(const DkConvDesc* d)

@@ -49,6 +49,9 @@ struct ConvArgs
   // Winograd F(2x2,3x3) (conv3x3_wino.hip): N counts 2x2 output tiles, tiles_w per row, tiles_hw per image
   int tiles_w, tiles_hw;
   double inv_tiles_w, inv_tiles_hw;
+  // ... raw-patch geometry: tile rows per image, column groups per staged row, rows per channel, loads per thread
+  int wino_th, wino_gp, wino_rs, wino_nk;
+  double inv_wino_th, inv_wino_gp, inv_wino_rsg;
 };
 
 // exact floor(n / d) for 0 <= n < 2^31, d > 0, given inv = 1.0 / d: the double estimate is within

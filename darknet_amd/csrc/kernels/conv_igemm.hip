@@ -976,9 +976,13 @@ int dk_conv_forward_cfg(const DkConvDesc* d, const float* x, const float* weight
       aw.w = wino_u;
       const int variant = dk_conv_wino_launch(aw, want - wino_base(), st);
       CHECK_HIP(hipPeekAtLastError());
-      dk_prof_end(ps, st, want * 4 + variant, 2.0 * (double)M * K * (double)a.N / 1e9);
-      continue;
+      dk_prof_end(ps, st, want * 4 + (variant < 0 ? 3 : variant), variant < 0 ? 0.0 : 2.0 * (double)M * K * (double)a.N / 1e9);
+      if (variant >= 0)
+        continue;
+      want = -1;   // raw-patch geometry does not fit the compiled load counts: take the direct kernel
     }
+    if (want < 0)
+      want = pick_direct(d, weights, M, a.N);
     if (want >= dma_base() && want < wino_base() && dk_conv_dma1x1_applicable(d, a.x, weights, want - dma_base()) &&
         !(dual && dual->m_split % dk_conv_dma1x1_bm(want - dma_base())))
     {

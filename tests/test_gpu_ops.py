@@ -334,7 +334,14 @@ WINO_CASES = [
     (2, 128, 76, 76, 128, "MISH", True),    # yolov4's most frequent shape
     (1, 512, 19, 19, 512, "LEAKY", False),  # long K (64 stages), partitioned launch (U > 3 MB)
     (5, 16, 6, 10, 64, "LOGISTIC", False),  # generic activation path, tiles straddling images
-    (1, 24, 2, 2, 192, "RELU", False),      # one tile per image
+    (3, 24, 4, 4, 192, "RELU", False),      # four tiles per image: 33 tile rows per strip
+    (1, 8, 152, 152, 64, "LEAKY", True),    # wide rows (76 tiles > 64 per strip): windowed raw patch, 16-byte loads
+    (1, 16, 304, 304, 64, "MISH", False),   # yolov4 layer 6's map: strips start mid-row at odd and even tiles
+    (2, 32, 38, 38, 64, "LEAKY", True),     # 8-byte row loads (W % 4 == 2)
+    (3, 16, 26, 26, 64, "MISH", False),     # yolov4-tiny map, 8-byte loads, 6 tile rows per strip
+    (2, 16, 52, 52, 128, "LEAKY", True),    # 16-byte loads with bank-padding rows
+    (1, 8, 130, 130, 64, "LINEAR", False),  # 65 tiles per row: wide case with 8-byte loads
+    (2, 8, 17, 23, 64, "LEAKY", False),     # non-square odd map, 4-byte loads
 ]
 
 
@@ -374,4 +381,6 @@ def test_conv_winograd_vs_oracle(gpu, case):
     L.dk_profile_read(out, 256)
     L.dk_profile_enable(0)
     for cfg in wino:
-        assert out[cfg * 4 * 3] + out[(cfg * 4 + 1) * 3] == 1, "config %s did not launch" % names[cfg]
+        # variants 0-2 = 16 / 8 / 4-byte row loads; slot 3 books a launch that fell back to the direct kernel
+        assert sum(out[(cfg * 4 + v) * 3] for v in range(3)) == 1 and out[(cfg * 4 + 3) * 3] == 0, \
+            "config %s did not launch" % names[cfg]

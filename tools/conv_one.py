@@ -18,6 +18,11 @@ dx = dk.DeviceArray(rng.uniform(-1, 1, b * c * h * w).astype(np.float32))
 dw = dk.DeviceArray((rng.uniform(-1, 1, n * c * size * size) * 0.05).astype(np.float32))
 db = dk.DeviceArray(rng.uniform(-1, 1, n).astype(np.float32))
 dy = dk.DeviceArray(n=b * n * oh * ow)
+nu = L.dk_conv_wino_weights_size(C.byref(d))
+if nu:   # Winograd configurations need the transformed filters
+    du = dk.DeviceArray(n=nu)
+    L.dk_conv_wino_transform_weights(C.byref(d), dw.ptr, du.ptr, None)
+    L.dk_conv_wino_register(dw.ptr, du.ptr)
 L.dk_conv_force_config(cfg)
 for _ in range(iters):
     L.dk_conv_forward(C.byref(d), dx.ptr, dw.ptr, db.ptr, dy.ptr, None, None, None)
