@@ -49,7 +49,7 @@
 #include "dk_internal.h"
 
 // diagnostic ablation builds (tools/build_ablate_wino.sh; results are garbage by construction):
-// bit 0 no input loads, 1 no filter loads, 2 no input transform / V writes, 3 no U writes, 4 no raw-patch writes
+// bit 0 no input DMA, 1 no filter DMA, 2 no input transform / V writes
 #ifndef DK_WABL
 #define DK_WABL 0
 #endif
@@ -58,34 +58,86 @@ namespace
 {
 constexpr int WBM = 64;              // filters per workgroup
 constexpr int WBN = 64;              // output tiles (2x2 pixels each) per workgroup
-constexpr int WCK = 8;               // input channels per stage
-constexpr int W_STAGE = 16 * 64 * WCK;  // floats of one operand's stage image (32 KB)
+constexpr int WCK = 4;               // input channels per stage
+constexpr int W_STAGE = 16 * 64 * WCK;  // floats of one operand's stage image (16 KB)
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f32x16 mfma2(float a, float b, f32x16 c)
 {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// element offset of (xi, sub-block, row r32, channel c8) inside a stage image
-__host__ __device__ __forceinline__ int img_off(int xi, int sub, int r32, int c8)
+// element offset of (xi, sub-block, row r32, channel c4) inside a stage image:
+// [xi][sub-block][channel pair][32 rows][2 floats] -- a lane's MFMA operands of one position are one ds_read_b64
+__host__ __device__ __forceinline__ int img_off(int xi, int sub, int r32, int c4)
 {
-  return xi * 512 + sub * 256 + (c8 >> 2) * 128 + r32 * 4 + (c8 & 3);
+  return xi * 256 + sub * 128 + (c4 >> 1) * 64 + r32 * 2 + (c4 & 1);
 }
 
-// loads per thread and stage of the raw patch the kernel is compiled for (host: wino_geometry)
-constexpr int wino_kmax(int vw) { return vw == 4 ? 15 : (vw == 2 ? 20 : 28); }
+// LDS-DMA pieces per thread and stage of the raw patch the kernel is compiled for (host: wino_geometry)
+constexpr int wino_kmax(int vw) { return vw == 4 ? 6 : 18; }
+
+// One LDS-DMA wave instruction: 64 lanes x 16 (4) bytes from buffer `rsrc` at byte offset voff (per lane;
+// out of range = dropped) to LDS bytes [lds_addr, lds_addr + 1024 (256)), lane-linear.  Inline asm on
+// purpose (as in conv1x1_dma.hip): hipcc must not count these in its own vmcnt bookkeeping, the kernel's
+// counted waits are the only ones.  M0 (the LDS destination) is written and restored inside the statement.
+__device__ __forceinline__ void dma16(u32x4_t rsrc, unsigned lds_addr, unsigned voff)
+{
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 4\n\t"
+               "buffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "s"(lds_addr), "v"(voff), "s"(rsrc)
+               : "memory");
+}
+__device__ __forceinline__ void dma4(u32x4_t rsrc, unsigned lds_addr, unsigned voff)
+{
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 4\n\t"
+               "buffer_load_dword %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "s"(lds_addr), "v"(voff), "s"(rsrc)
+               : "memory");
+}
+__device__ __forceinline__ u32x4_t make_rsrc(const void* base, unsigned bytes)
+{
+  const unsigned long long a = (unsigned long long)base;
+  u32x4_t r;
+  r.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+  r.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);   // stride 0
+  r.z = __builtin_amdgcn_readfirstlane(bytes);
+  r.w = 0x00020000u;
+  return r;
+}
+// s_waitcnt vmcnt(n) for a wave-uniform n (the immediate must be a constant)
+__device__ __forceinline__ void wait_vmcnt_n(int n)
+{
+#define DK_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+  switch (n)
+  {
+    DK_W(0) DK_W(1) DK_W(2) DK_W(3) DK_W(4) DK_W(5) DK_W(6) DK_W(7) DK_W(8) DK_W(9) DK_W(10) DK_W(11) DK_W(12)
+    DK_W(13) DK_W(14) DK_W(15) DK_W(16) DK_W(17) DK_W(18) DK_W(19) DK_W(20) DK_W(21) DK_W(22) DK_W(23) DK_W(24)
+    DK_W(25) DK_W(26) DK_W(27) DK_W(28) DK_W(29) DK_W(30) DK_W(31) DK_W(32) DK_W(33) DK_W(34) DK_W(35) DK_W(36)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef DK_W
+}
+// workgroup barrier that leaves LDS-DMA in flight (a __syncthreads() would drain vmcnt)
+__device__ __forceinline__ void barrier_lds()
+{
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 template <int VW, bool PAIR>
 __global__ void __launch_bounds__(256) conv3x3_wino_f32(const ConvArgs p)
 {
   constexpr int KMAX = wino_kmax(VW);
-  constexpr int SH = (VW & 1) ? 0 : 1;   // raw rows start one float in when VW is even: tile columns stay 8-byte aligned
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* const Us = lds;                 // [W_STAGE]      filters of the stage being multiplied
-  float* const Vs = lds + W_STAGE;       // [2][W_STAGE]   transformed input, double-buffered
-  float* const Rs = lds + 3 * W_STAGE;   // raw input rows of the NEXT stage: [8 ch][RS rows][Pw]
+  float* const Us = lds;                 // [3][W_STAGE]  transformed filters, LDS-DMA ring
+  float* const Vs = lds + 3 * W_STAGE;   // [2][W_STAGE]  transformed input, double-buffered
+  float* const Rs = lds + 5 * W_STAGE;   // [3][RAWF]     raw input rows, LDS-DMA ring: [4 ch][RS rows][Pw]
 
   int g, tile_m, tile_n;
   if (!conv_block_tile(p, g, tile_m, tile_n))
@@ -100,9 +152,13 @@ __global__ void __launch_bounds__(256) conv3x3_wino_f32(const ConvArgs p)
   const int TW = p.tiles_w, THW = p.tiles_hw, TH = p.wino_th;
   const int GP = p.wino_gp, RS = p.wino_rs, NK = p.wino_nk;
   const int Pw = VW * GP;
+  const int RAWF = NK * 256 * VW;
 
-  __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+  const u32x4_t xr = make_rsrc(p.x, p.x_bytes);
+  const u32x4_t ur = make_rsrc(p.w, p.w_bytes);
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)lds);
+  const unsigned u_lds = lds0 + (unsigned)(wave * 64) * 16u;                               // + slot * 16 KB + j * 4 KB
+  const unsigned r_lds = lds0 + (unsigned)(5 * W_STAGE) * 4u + (unsigned)(wave * 64 * VW) * 4u;   // + slot * RAWF * 4 + k * 256 * VW * 4
 
   // ---- geometry of the strip: tile rows R0 .. Rlast (R = b * TH + ty), first tile column tx0 ----
   const int R0 = fdiv(n0, TW, p.inv_tiles_w);
@@ -113,7 +169,9 @@ __global__ void __launch_bounds__(256) conv3x3_wino_f32(const ConvArgs p)
   // first loaded column group of local tile row r: floor((2 * txs - 1) / VW), txs = first tile column staged
   auto g0_of = [&](int r) { const int txs = (wide && r == 0) ? tx0 : 0; return (2 * txs - 1 + VW) / VW - 1; };
 
-  // ---- raw patch loads: element e = tid + 256 * k is column group g of row (c, r, i) ------------
+  // ---- raw patch pieces: element e = tid + 256 * k is column group g of row (c, r, i) ------------
+  // Padding and ragged edges get an out-of-range source offset: the DMA drops them and the zeros written
+  // once below stay (the geometry of a piece does not depend on the stage).
   unsigned xoff[KMAX];
 #pragma unroll
   for (int k = 0; k < KMAX; ++k)
@@ -133,23 +191,19 @@ __global__ void __launch_bounds__(256) conv3x3_wino_f32(const ConvArgs p)
     xoff[k] = ok ? (unsigned)(((b * p.Ctot + c) * p.H + iy) * p.W + col0) * 4u : OOB;
   }
 
-  // ---- input-transform ownership: two (channel, tile) pairs per thread ------------------------
-  // lane -> channel (lane & 3) + 4 * (lane >> 5), tile ((lane >> 2) & 7) of an 8-tile group;
-  // wave w, pass q -> tile group 2w + q.  (The 32 lanes of a half-wave then write 32 distinct
-  // LDS banks for every position, and read 64 distinct banks of the raw patch with ds_read_b64
-  // when the host could make the channel stride RS * Pw = 16 mod 32 floats.)
-  const int c8 = (lane & 3) + 4 * lh;
-  int rsrc[2], vdst[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q)
+  // ---- input-transform ownership: one (channel, tile) pair per thread -------------------------
+  // lane -> channel (lane & 1) + 2 * (lane >> 5), tile (lane >> 1) & 15 of the wave's 16 tiles: the 32
+  // lanes of a half-wave write 32 consecutive floats of every position (no bank conflicts).
+  const int c4 = (lane & 1) + 2 * lh;
+  int rsrc, vdst;
   {
-    const int tl = (wave * 2 + q) * 8 + ((lane >> 2) & 7);
+    const int tl = wave * 16 + ((lane >> 1) & 15);
     const int n = (n0 + tl < p.N) ? n0 + tl : nlast;
     const int R = fdiv(n, TW, p.inv_tiles_w);
     const int tx = n - R * TW;
     const int r = R - R0;
-    rsrc[q] = (c8 * RS + 4 * r) * Pw + 2 * tx - 1 - VW * g0_of(r) + SH;
-    vdst[q] = img_off(0, tl >> 5, tl & 31, c8);
+    rsrc = (c4 * RS + 4 * r) * Pw + 2 * tx - 1 - VW * g0_of(r);
+    vdst = img_off(0, tl >> 5, tl & 31, c4);
   }
   const unsigned stage_x_bytes = (unsigned)(WCK * p.H * p.W) * 4u;
   const unsigned ubase = (unsigned)(tile_m * nst) * (unsigned)(W_STAGE * 4) + (unsigned)tid * 16u;
@@ -160,71 +214,65 @@ __global__ void __launch_bounds__(256) conv3x3_wino_f32(const ConvArgs p)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-  float raw[KMAX][VW];
-  float4 ureg[8];
-  auto load_raw = [&](int t) {
-    const unsigned xo = (unsigned)t * stage_x_bytes;
+  // zero the raw ring once (padding positions are never written again)
+  for (int i = tid; i < 3 * RAWF; i += 256) Rs[i] = 0.f;
+  barrier_lds();
+
+  // LDS-DMA issue: raw rows of stage s into ring slot s % 3, filters of stage s into ring slot s % 3
+  auto issue_raw = [&](int s) {
+    const unsigned xo = (unsigned)s * stage_x_bytes;
+    const unsigned dst = r_lds + (unsigned)((s % 3) * RAWF) * 4u;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k)
-    {
-      if (k < NK)
+      if (k < NK && !(DK_WABL & 1))
       {
-        if (DK_WABL & 1)
-        {
-#pragma unroll
-          for (int j = 0; j < VW; ++j) raw[k][j] = 1.f;
-        }
-        else if constexpr (VW == 4)
-        {
-          const float4 v = ld_buf4(xr, xoff[k] + xo);
-          raw[k][0] = v.x; raw[k][1] = v.y; raw[k][2] = v.z; raw[k][3] = v.w;
-        }
-        else if constexpr (VW == 2)
-        {
-          const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(xr, (int)(xoff[k] + xo), 0, 0);
-          raw[k][0] = __uint_as_float(v.x); raw[k][1] = __uint_as_float(v.y);
-        }
+        if constexpr (VW == 4)
+          dma16(xr, dst + (unsigned)k * 4096u, xoff[k] + xo);
         else
-          raw[k][0] = ld_buf(xr, xoff[k] + xo);
+          dma4(xr, dst + (unsigned)k * 1024u, xoff[k] + xo);
       }
-    }
   };
-  auto write_raw = [&]() {
+  auto issue_u = [&](int s) {
+    const unsigned uo = ubase + (unsigned)s * (unsigned)(W_STAGE * 4);
+    const unsigned dst = u_lds + (unsigned)((s % 3) * W_STAGE) * 4u;
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k)
-    {
-      if (k < NK && !(DK_WABL & 16))
-      {
-        float* const dst = Rs + VW * (tid + 256 * k) + SH;
-#pragma unroll
-        for (int j = 0; j < VW; ++j) dst[j] = raw[k][j];
-      }
-    }
+    for (int j = 0; j < 4; ++j)
+      if (!(DK_WABL & 2))
+        dma16(ur, dst + (unsigned)j * 4096u, uo + (unsigned)j * 4096u);
   };
-  auto load_u = [&](int t) {
-    const unsigned uo = ubase + (unsigned)t * (unsigned)(W_STAGE * 4);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ureg[j] = (DK_WABL & 2) ? make_float4(1.f, 1.f, 1.f, 1.f) : ld_buf4(ur, uo + (unsigned)j * 4096u);
-  };
-  auto write_u = [&]() {
-#pragma unroll
-    for (int j = 0; j < ((DK_WABL & 8) ? 0 : 8); ++j) ((float4*)Us)[tid + j * 256] = ureg[j];
+  // bundle B(s) = {filters of stage s, raw rows of stage s + 1}: both are first needed in iteration s
+  const int cnt_u = (DK_WABL & 2) ? 0 : 4, cnt_r = (DK_WABL & 1) ? 0 : NK;
+  auto bundle_count = [&](int s) { return (s < nst ? cnt_u : 0) + (s + 1 < nst ? cnt_r : 0); };
+  auto issue_bundle = [&](int s) {
+    if (s < nst)
+      issue_u(s);
+    if (s + 1 < nst)
+      issue_raw(s + 1);
   };
 
-  // V = B^T d B of this thread's two patches, cut into 16 slices (pair q = s / 8): slices 0-3 of a
-  // pair request the four patch rows, slice 4 applies (d B) to the rows, slices 4-7 finish one
-  // row of B^T (..) each and write its four positions.
+  // V = B^T d B of this thread's patch, cut into 8 slices: slices 0-3 request the four patch rows,
+  // slice 4 applies (d B) to the rows, slices 4-7 finish one row of B^T (..) each and write its four positions.
   float dd[4][4], ww[4][4];
-  auto tslice = [&](auto sc, float* Vnext) {
-    constexpr int sidx = decltype(sc)::value;
-    constexpr int q = sidx >> 3, part = sidx & 7;
+  auto tslice = [&](auto sc, const float* Rcur, float* Vnext) {
+    constexpr int part = decltype(sc)::value;
     if (DK_WABL & 4)
       return;
     if constexpr (part < 4)
     {
-      const float2* const src = (const float2*)(Rs + rsrc[q] + part * Pw);
-      const float2 lo = src[0], hi = src[1];
-      dd[part][0] = lo.x; dd[part][1] = lo.y; dd[part][2] = hi.x; dd[part][3] = hi.y;
+      const float* const src = Rcur + rsrc + part * Pw;
+      if constexpr (VW == 4)
+      {
+        // patch column 2 tx - 1 sits at an odd float: b32, aligned b64, b32
+        const float d0 = src[0];
+        const float2 mid = *(const float2*)(src + 1);
+        const float d3 = src[3];
+        dd[part][0] = d0; dd[part][1] = mid.x; dd[part][2] = mid.y; dd[part][3] = d3;
+      }
+      else
+      {
+        const float2 lo = *(const float2*)src, hi = *(const float2*)(src + 2);
+        dd[part][0] = lo.x; dd[part][1] = lo.y; dd[part][2] = hi.x; dd[part][3] = hi.y;
+      }
     }
     else
     {
@@ -240,55 +288,47 @@ __global__ void __launch_bounds__(256) conv3x3_wino_f32(const ConvArgs p)
         }
       }
       constexpr int i = part - 4;
-      float* const dst = Vnext + vdst[q] + i * 4 * 512;
+      float* const dst = Vnext + vdst + i * 4 * 256;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
       {
         const float v = i == 0 ? ww[0][j] - ww[2][j] : i == 1 ? ww[1][j] + ww[2][j] : i == 2 ? ww[2][j] - ww[1][j] : ww[1][j] - ww[3][j];
-        dst[j * 512] = v;
+        dst[j * 256] = v;
       }
     }
   };
-  auto tslices4 = [&](auto gc, float* Vnext) {   // the four slices that accompany MFMA group gc
-    constexpr int s0 = decltype(gc)::value * 4;
-    tslice(std::integral_constant<int, s0>(), Vnext);
-    tslice(std::integral_constant<int, s0 + 1>(), Vnext);
-    tslice(std::integral_constant<int, s0 + 2>(), Vnext);
-    tslice(std::integral_constant<int, s0 + 3>(), Vnext);
-  };
 
-  // ---- prologue: raw(0) -> LDS, V(0) ----------------------------------------------------------
-  load_raw(0);
-  write_raw();
-  __syncthreads();
-  if (nst > 1)
-    load_raw(1);
-  load_u(0);
-  tslices4(std::integral_constant<int, 0>(), Vs);
-  tslices4(std::integral_constant<int, 1>(), Vs);
-  tslices4(std::integral_constant<int, 2>(), Vs);
-  tslices4(std::integral_constant<int, 3>(), Vs);
+  // ---- prologue: raw(0), B(0), B(1) in flight; V(0) from raw(0) --------------------------------
+  issue_raw(0);
+  issue_bundle(0);
+  issue_bundle(1);
+  wait_vmcnt_n(bundle_count(0) + bundle_count(1));
+  barrier_lds();
+  tslice(std::integral_constant<int, 0>(), Rs, Vs);
+  tslice(std::integral_constant<int, 1>(), Rs, Vs);
+  tslice(std::integral_constant<int, 2>(), Rs, Vs);
+  tslice(std::integral_constant<int, 3>(), Rs, Vs);
+  tslice(std::integral_constant<int, 4>(), Rs, Vs);
+  tslice(std::integral_constant<int, 5>(), Rs, Vs);
+  tslice(std::integral_constant<int, 6>(), Rs, Vs);
+  tslice(std::integral_constant<int, 7>(), Rs, Vs);
 
-  const float4* const Ua = (const float4*)Us + wm * 64 + lh * 32 + l31;
   for (int t = 0; t < nst; ++t)
   {
-    // A: V(t) complete, every read of raw(t) and of U(t-1) done
-    __syncthreads();
-    if (t + 1 < nst)
-      write_raw();   // raw(t+1)
-    write_u();       // U(t)
-    __syncthreads();
-    if (t + 2 < nst)
-      load_raw(t + 2);
-    if (t + 1 < nst)
-      load_u(t + 1);
-    const float4* const Va = (const float4*)(Vs + (t & 1) * W_STAGE) + wn * 64 + lh * 32 + l31;
+    // B(t) has landed for this wave; behind the barrier for every wave, and every wave has left
+    // iteration t - 1 (V(t) complete; ring slots of U(t-1) and raw(t) free)
+    wait_vmcnt_n(bundle_count(t + 1));
+    barrier_lds();
+    issue_bundle(t + 2);
+    const float2* const Ua = (const float2*)(Us + (t % 3) * W_STAGE) + wm * 64 + lh * 32 + l31;
+    const float2* const Va = (const float2*)(Vs + (t & 1) * W_STAGE) + wn * 64 + lh * 32 + l31;
+    const float* const Rcur = Rs + ((t + 1) % 3) * RAWF;
     float* const Vnext = Vs + ((t + 1) & 1) * W_STAGE;
-    // ---- 16 positions x 4 k-pairs, four positions at a time with their MFMAs interleaved; the
+    // ---- 16 positions x 2 k-pairs, four positions at a time with their MFMAs interleaved; the
     // fragments of the next group are requested before the MFMAs of the current one are issued,
-    // and between the four MFMA rounds of a group sits one slice of the NEXT stage's input
-    // transform (after the last stage it works on stale rows into the unused V half: harmless).
-    float4 fa[2][4], fb[2][4];
+    // and behind each MFMA round sits one slice of the NEXT stage's input transform (after the
+    // last stage it works on stale rows into the unused V half: harmless).
+    float2 fa[2][4], fb[2][4];
 #pragma unroll
     for (int u = 0; u < 4; ++u)
     {
@@ -309,19 +349,11 @@ __global__ void __launch_bounds__(256) conv3x3_wino_f32(const ConvArgs p)
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < 4; ++u) acc[grp * 4 + u] = mfma2(fa[grp & 1][u].x, fb[grp & 1][u].x, acc[grp * 4 + u]);
-      tslice(std::integral_constant<int, grp * 4 + 0>(), Vnext);
+      tslice(std::integral_constant<int, grp * 2 + 0>(), Rcur, Vnext);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < 4; ++u) acc[grp * 4 + u] = mfma2(fa[grp & 1][u].y, fb[grp & 1][u].y, acc[grp * 4 + u]);
-      tslice(std::integral_constant<int, grp * 4 + 1>(), Vnext);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) acc[grp * 4 + u] = mfma2(fa[grp & 1][u].z, fb[grp & 1][u].z, acc[grp * 4 + u]);
-      tslice(std::integral_constant<int, grp * 4 + 2>(), Vnext);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) acc[grp * 4 + u] = mfma2(fa[grp & 1][u].w, fb[grp & 1][u].w, acc[grp * 4 + u]);
-      tslice(std::integral_constant<int, grp * 4 + 3>(), Vnext);
+      tslice(std::integral_constant<int, grp * 2 + 1>(), Rcur, Vnext);
       __builtin_amdgcn_sched_barrier(0);
     };
     group(std::integral_constant<int, 0>());
@@ -470,8 +502,8 @@ std::mutex g_reg_mu;
 std::unordered_map<const float*, const float*> g_reg;  // layer weights (device) -> transformed filters
 }  // namespace
 
-// Raw-patch geometry of a launch (see the kernel): vector width of the row loads, column groups
-// per row (gp), rows per channel incl. bank padding (rs), loads per thread and stage (nk).
+// Raw-patch geometry of a launch (see the kernel): vector width of the row pieces, column groups
+// per row (gp), rows per channel incl. bank padding (rs), DMA pieces per thread and stage (nk).
 struct WinoGeo
 {
   int vw, gp, rs, nk;
@@ -490,10 +522,10 @@ bool wino_geometry(int TW, int vw, WinoGeo& o)
     int rs = rows;
     if (pass == 0)
     {
-      // channel stride = 16 mod 32 floats: the four channels of a half-wave read disjoint banks
+      // channel stride = 32 mod 64 floats: the two channels of a half-wave read disjoint banks
       rs = -1;
       for (int cand = rows; cand <= rows + 8; ++cand)
-        if ((cand * vw * gp) % 32 == 16)
+        if ((cand * vw * gp) % 64 == 32)
         {
           rs = cand;
           break;
@@ -511,12 +543,10 @@ bool wino_geometry(int TW, int vw, WinoGeo& o)
   return false;
 }
 
-// widest row vector the layer's width admits that also fits the compiled load count
-bool wino_pick(int W, int TW, bool aligned16, bool aligned8, WinoGeo& o)
+// 16-byte pieces when the rows are 16-byte aligned (W % 4 == 0), else 4-byte pieces
+bool wino_pick(int W, int TW, bool aligned16, WinoGeo& o)
 {
   if (W % 4 == 0 && aligned16 && wino_geometry(TW, 4, o))
-    return true;
-  if (W % 2 == 0 && aligned8 && wino_geometry(TW, 2, o))
     return true;
   return wino_geometry(TW, 1, o);
 }
@@ -525,13 +555,13 @@ int dk_conv_wino_num_configs() { return 1; }
 const char* dk_conv_wino_config_name(int c) { return c == 0 ? "wino_64x64" : nullptr; }
 const char* dk_conv_wino_kernel_name(int c, int variant)
 {
-  static const char* names[3] = {"conv3x3_wino_f32<4, true>", "conv3x3_wino_f32<2, true>", "conv3x3_wino_f32<1, false>"};
+  static const char* names[3] = {"conv3x3_wino_f32<4, true>", "conv3x3_wino_f32<1, true>", "conv3x3_wino_f32<1, false>"};
   return (c == 0 && variant >= 0 && variant < 3) ? names[variant] : nullptr;
 }
 bool dk_conv_wino_applicable(const DkConvDesc* d, int c)
 {
   WinoGeo o;
-  return c == 0 && shape_ok(d) && wino_pick(d->w, (d->w + 1) / 2, true, true, o);
+  return c == 0 && shape_ok(d) && wino_pick(d->w, (d->w + 1) / 2, true, o);
 }
 
 const float* dk_conv_wino_lookup(const float* weights)
@@ -542,7 +572,8 @@ const float* dk_conv_wino_lookup(const float* weights)
 }
 
 // Launches one batch chunk; a.w must already point at the transformed filters.  Returns the variant
-// (0: 16-byte row loads, 1: 8-byte, 2: 4-byte), or -1 when the geometry does not fit (caller falls back).
+// (0: 16-byte row pieces, 1: 4-byte pieces / paired stores, 2: 4-byte pieces / single stores), or -1 when the
+// geometry does not fit (caller falls back).
 int dk_conv_wino_launch(ConvArgs a, int c, hipStream_t st)
 {
   (void)c;
@@ -550,8 +581,8 @@ int dk_conv_wino_launch(ConvArgs a, int c, hipStream_t st)
   const int nb = a.N / a.OHW;
   const bool pair = (a.OW % 2 == 0) && (((uintptr_t)a.y & 7) == 0) && (!a.residual || ((uintptr_t)a.residual & 7) == 0);
   WinoGeo o;
-  const bool a16 = pair && ((uintptr_t)a.x & 15) == 0, a8 = pair && ((uintptr_t)a.x & 7) == 0;
-  if (!wino_pick(a.W, TW, a16, a8, o))
+  const bool a16 = pair && ((uintptr_t)a.x & 15) == 0;
+  if (!wino_pick(a.W, TW, a16, o))
     return -1;
   a.tiles_w = TW;
   a.tiles_hw = TH * TW;
@@ -574,11 +605,11 @@ int dk_conv_wino_launch(ConvArgs a, int c, hipStream_t st)
   const long long nblk = conv_pick_partition(a, (size_t)a.w_bytes, WBM);
   if (drop_w)
     a.w_bytes = 0;
-  const int bytes = (3 * W_STAGE + o.nk * 256 * o.vw + 8) * (int)sizeof(float);
-  void (*k)(const ConvArgs) = o.vw == 4 ? conv3x3_wino_f32<4, true> : (o.vw == 2 ? conv3x3_wino_f32<2, true> : conv3x3_wino_f32<1, false>);
+  const int bytes = (5 * W_STAGE + 3 * o.nk * 256 * o.vw) * (int)sizeof(float);
+  void (*k)(const ConvArgs) = o.vw == 4 ? conv3x3_wino_f32<4, true> : (pair ? conv3x3_wino_f32<1, true> : conv3x3_wino_f32<1, false>);
   dk_set_max_dynamic_lds((const void*)k, bytes);
   hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), bytes, st, a);
-  return o.vw == 4 ? 0 : (o.vw == 2 ? 1 : 2);
+  return o.vw == 4 ? 0 : (pair ? 1 : 2);
 }
 
 extern "C" size_t dk_conv_wino_weights_size(const DkConvDesc* d)
