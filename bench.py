@@ -44,12 +44,17 @@ CFG = "yolov4"
 BATCH_PER_GPU = 16
 
 
-def pmc_traffic_for(kernel):
-    """HBM bytes per launch of `kernel` from the newest committed PMC summary
-    (profiles/*pmc_traffic*.json, produced by tools/pmc_traffic.sh on this workload);
-    None when no summary names the kernel."""
+def pmc_traffic_for(kernel, tag=None):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary of THIS workload
+    (profiles/round*_<tag>/traffic_summary.json, produced by tools/make_profiles.sh with this command line:
+    FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc passes); older rounds' summaries are the fallback.
+    None when no summary names the kernel (e.g. the tuner picked a kernel the profiled run did not use)."""
     import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
+    files = []
+    if tag:
+        files += sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_%s" % tag, "traffic_summary.json")), reverse=True)
+    files += sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True)
+    for f in files:
         try:
             for r in json.load(open(f)):
                 if kernel in r["kernel"]:
@@ -169,13 +174,17 @@ def main():
     frames = (np.clip(x.reshape(args.batch, net.c, net.h, net.w), 0, 1) * 255).astype(np.uint8)
     frames = np.ascontiguousarray(frames.transpose(0, 2, 3, 1))
 
+    # double-buffered input step: while the forward of batch k runs, batch k+1 is copied to pinned memory
+    # and crosses PCIe on the copy stream (DkNetworkStageU8); the boxes of batch k are collected after that
     def u8_step():
-        net.predict_u8(frames)
+        net.predict_staged()      # device Mat2Image of the staged frames + forward (asynchronous)
+        net.stage_u8(frames)      # next batch: host copy + H2D, overlapped with the forward above
         n = 0
         for b in range(args.batch):
             n += len(net.boxes(b, box_thresh, max_dets=2048)[0])
         return n
 
+    net.stage_u8(frames)
     u8_step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -202,15 +211,20 @@ def main():
         tot_gf = sum(r[2] for r in rows)
         achieved = gflop / ms  # GFLOP / ms = TFLOP/s
         kname = L.dk_conv_kernel_name(ci).decode()
-        traffic = pmc_traffic_for(kname)
+        # profiles/round<N>_{c3,c2,c5}: the BASELINE configs the summaries were taken on
+        tag = {"yolov4": "c3", "yolov4-tiny": "c2", "yolov4-csp": "c5"}.get(args.cfg)
+        traffic = pmc_traffic_for(kname, tag)
         # the dominant kernel's own arithmetic decides its roof: fp16-operand kernels run on the fp16 MFMA pipe
         peak = FP16_MFMA_PEAK_TFLOPS if "f16" in kname else FP32_MFMA_PEAK_TFLOPS
         roofline = {
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
             "frac": achieved / peak, "traffic": traffic,
             "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate "
-                            "rocprofv3 --pmc passes of this command: tools/pmc_traffic.sh -> profiles/)",
+                            "rocprofv3 --pmc passes of this command: tools/make_profiles.sh -> profiles/round*/)",
             "kernel": kname,
+            # Winograd launches are booked with the DIRECT algorithm's FLOPs (SURVEY 8d's per-layer figure):
+            # `achieved` is algorithmic; the MFMA pipe executes 2.25x fewer
+            "mfma_executed_tflops": achieved / 2.25 if "wino" in kname else achieved,
             "launches_per_step": launches / prof_steps,
             "gflop_per_launch": gflop / launches, "avg_launch_ms": ms / launches,
             "all_conv_kernels": {"achieved": tot_gf / tot_ms, "frac": tot_gf / tot_ms / FP32_MFMA_PEAK_TFLOPS,

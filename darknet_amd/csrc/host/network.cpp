@@ -665,30 +665,81 @@ float* NetworkPredict(Network* net, float* input) { return NetworkPredictGpu(net
 
 // the input step before the path.  The frames cross PCIe as bytes (4x fewer
 // than floats) and Mat2Image's arithmetic runs on the device.
-void DkNetworkPredictU8(Network* net, const unsigned char* frames_hwc, size_t row_step)
+void DkNetworkStageU8(Network* net, const unsigned char* frames_hwc, size_t row_step)
 {
   if (net->gpu_index < 0)
-    error("DkNetworkPredictU8: no HIP device (this library has no CPU fallback)");
+    error("DkNetworkStageU8: no HIP device (this library has no CPU fallback)");
   if (net->gpu_index != cuda_get_device())
     cuda_set_device(net->gpu_index);
   if (row_step < (size_t)net->w * net->c)
-    error("DkNetworkPredictU8: row_step smaller than one row");
+    error("DkNetworkStageU8: row_step smaller than one row");
   const size_t bytes = row_step * net->h * net->batch;
   if (net->u8_bytes < bytes)
   {
+    NetworkSync(net);
     if (net->u8_gpu) CHECK_HIP(hipFree(net->u8_gpu));
     if (net->u8_pinned) CHECK_HIP(hipHostFree(net->u8_pinned));
+    if (net->u8_gpu2) CHECK_HIP(hipFree(net->u8_gpu2));
+    if (net->u8_pinned2) CHECK_HIP(hipHostFree(net->u8_pinned2));
     CHECK_HIP(hipMalloc((void**)&net->u8_gpu, bytes));
     CHECK_HIP(hipHostMalloc((void**)&net->u8_pinned, bytes, hipHostMallocDefault));
+    CHECK_HIP(hipMalloc((void**)&net->u8_gpu2, bytes));
+    CHECK_HIP(hipHostMalloc((void**)&net->u8_pinned2, bytes, hipHostMallocDefault));
     net->u8_bytes = bytes;
+    net->u8_conv_pending[0] = net->u8_conv_pending[1] = 0;
   }
+  for (int i = 0; i < 2; ++i)
+    if (!net->u8_h2d_ev[i])
+    {
+      hipEvent_t a, b;
+      CHECK_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+      CHECK_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+      net->u8_h2d_ev[i] = a;
+      net->u8_conv_ev[i] = b;
+    }
+  const int slot = net->u8_next & 1;
+  // the conversion that last read this slot (two stage calls ago) must be done before its buffers are reused
+  if (net->u8_conv_pending[slot])
+  {
+    CHECK_HIP(hipEventSynchronize((hipEvent_t)net->u8_conv_ev[slot]));
+    net->u8_conv_pending[slot] = 0;
+  }
+  unsigned char* pinned = slot ? net->u8_pinned2 : net->u8_pinned;
+  unsigned char* dev = slot ? net->u8_gpu2 : net->u8_gpu;
+  memcpy(pinned, frames_hwc, bytes);
+  hipStream_t cs = get_cuda_memcpy_stream();
+  CHECK_HIP(hipMemcpyAsync(dev, pinned, bytes, hipMemcpyHostToDevice, cs));
+  CHECK_HIP(hipEventRecord((hipEvent_t)net->u8_h2d_ev[slot], cs));
+  net->u8_staged = slot + 1;
+  net->u8_row_step = row_step;
+  net->u8_next = slot ^ 1;
+}
+
+void DkNetworkPredictStaged(Network* net)
+{
+  if (net->gpu_index < 0)
+    error("DkNetworkPredictStaged: no HIP device (this library has no CPU fallback)");
+  if (net->u8_staged < 1)
+    error("DkNetworkPredictStaged: no frames staged (call DkNetworkStageU8 first)");
+  if (net->gpu_index != cuda_get_device())
+    cuda_set_device(net->gpu_index);
+  const int slot = net->u8_staged - 1;
   hipStream_t st = get_cuda_stream();
-  CHECK_HIP(hipStreamSynchronize(st));  // the previous call's H2D out of the staging buffer is done
-  memcpy(net->u8_pinned, frames_hwc, bytes);
-  CHECK_HIP(hipMemcpyAsync(net->u8_gpu, net->u8_pinned, bytes, hipMemcpyHostToDevice, st));
-  if (dk_image_u8_to_chw(net->u8_gpu, net->input_state_gpu, net->batch, net->w, net->h, net->c, row_step, st))
+  // stream order already puts the conversion behind the previous forward's reads of the input tensor
+  CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)net->u8_h2d_ev[slot], 0));
+  if (dk_image_u8_to_chw(slot ? net->u8_gpu2 : net->u8_gpu, net->input_state_gpu, net->batch, net->w, net->h, net->c,
+          net->u8_row_step, st))
     error("dk_image_u8_to_chw failed");
+  CHECK_HIP(hipEventRecord((hipEvent_t)net->u8_conv_ev[slot], st));
+  net->u8_conv_pending[slot] = 1;
+  net->u8_staged = 0;
   NetworkPredictDevice(net, nullptr);
+}
+
+void DkNetworkPredictU8(Network* net, const unsigned char* frames_hwc, size_t row_step)
+{
+  DkNetworkStageU8(net, frames_hwc, row_step);
+  DkNetworkPredictStaged(net);
 }
 
 // ---------------------------------------------------------------------------
@@ -1128,6 +1179,13 @@ void FreeNetwork(Network* net)
     if (net->cand_host) cuda_free_host(net->cand_host);
     if (net->u8_gpu) (void)hipFree(net->u8_gpu);
     if (net->u8_pinned) (void)hipHostFree(net->u8_pinned);
+    if (net->u8_gpu2) (void)hipFree(net->u8_gpu2);
+    if (net->u8_pinned2) (void)hipHostFree(net->u8_pinned2);
+    for (int i = 0; i < 2; ++i)
+    {
+      if (net->u8_h2d_ev[i]) (void)hipEventDestroy((hipEvent_t)net->u8_h2d_ev[i]);
+      if (net->u8_conv_ev[i]) (void)hipEventDestroy((hipEvent_t)net->u8_conv_ev[i]);
+    }
   }
   free(net->cand_order);
   memset(net, 0, sizeof(*net));

@@ -65,6 +65,21 @@ class DkNet:
         self.L.DkNetworkPredictU8.restype = None
         self.L.DkNetworkPredictU8(self.p, frames.ctypes.data, row_step)
 
+    def stage_u8(self, frames, row_step=None):
+        """DkNetworkStageU8: pinned copy + H2D of the NEXT batch on the copy stream (overlaps the running forward)."""
+        frames = np.ascontiguousarray(frames, np.uint8)
+        if row_step is None:
+            row_step = self.w * self.c
+        assert frames.size == self.batch * self.h * row_step
+        self.L.DkNetworkStageU8.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        self.L.DkNetworkStageU8.restype = None
+        self.L.DkNetworkStageU8(self.p, frames.ctypes.data, row_step)
+
+    def predict_staged(self):
+        self.L.DkNetworkPredictStaged.argtypes = [C.c_void_p]
+        self.L.DkNetworkPredictStaged.restype = None
+        self.L.DkNetworkPredictStaged(self.p)
+
     def output(self, i):
         f = self.info(i)
         out = np.empty(f["batch"] * f["outputs"], np.float32)

@@ -288,9 +288,17 @@ struct Network
   float cand_nms;        /* NMS threshold the candidate records were suppressed with on the device (0: raw) */
   int cand_nms_done;
   void* nms_heads_gpu;   /* DkYoloHead[n] + overflow word (device NMS) */
-  unsigned char* u8_gpu; /* interleaved u8 frames on the device */
+  unsigned char* u8_gpu; /* interleaved u8 frames on the device (staging slot 0) */
   unsigned char* u8_pinned;
   size_t u8_bytes;
+  /* second staging slot + events of the double-buffered input step (DkNetworkStageU8 / DkNetworkPredictStaged) */
+  unsigned char* u8_gpu2;
+  unsigned char* u8_pinned2;
+  void* u8_h2d_ev[2];   /* H2D of slot i finished (copy stream) */
+  void* u8_conv_ev[2];  /* conversion kernel that read slot i finished (compute stream) */
+  int u8_conv_pending[2];
+  int u8_next, u8_staged; /* slot the next stage call fills; slot staged and not yet consumed (-1: none) + 1 */
+  size_t u8_row_step;
   float* delta_arena_gpu; /* train: every layer's delta_gpu lives in this one allocation (one memset per step) */
   size_t delta_arena_size;
   float* grad_bucket;    /* caller-owned contiguous gradient bucket (DkAttachGradBucket), or NULL */
@@ -498,6 +506,12 @@ LIB_API int DkLayerOutput(Network* net, int i, float* dst, size_t n); /* D2H cop
  * converted on the device (visualize.cpp:26-55 arithmetic).  Heads stay on the device; use
  * GetNetworkBoxesBatch (device extraction, DkSetPullHeads(0)) or DkSetPullHeads(1). */
 LIB_API void DkNetworkPredictU8(Network* net, const unsigned char* frames_hwc, size_t row_step);
+/* The same in two halves, double-buffered: DkNetworkStageU8 copies the NEXT batch of frames to pinned memory
+ * and starts its H2D on the copy stream (call it right after launching the current prediction: both overlap the
+ * forward pass that is running); DkNetworkPredictStaged converts the staged frames on the device and runs the
+ * forward.  DkNetworkPredictU8 == Stage + PredictStaged. */
+LIB_API void DkNetworkStageU8(Network* net, const unsigned char* frames_hwc, size_t row_step);
+LIB_API void DkNetworkPredictStaged(Network* net);
 LIB_API float* DkLayerOutputGpu(Network* net, int i);
 LIB_API float* DkLayerHostPtr(Network* net, int i, int which); /* 1 weights 2 biases 3 scales 4 mean 5 var */
 /* Flattened detections of batch item b: per det [x,y,w,h,obj,prob[classes]] and

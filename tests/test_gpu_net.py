@@ -209,6 +209,27 @@ def test_big_nets_b1_vs_golden(gpu, weights, name):
     net.close()
 
 
+def test_staged_u8_input_double_buffer(gpu, weights):
+    """DkNetworkStageU8 / DkNetworkPredictStaged (the double-buffered input step): staging batch k+1 while the
+    forward of batch k is in flight must not disturb batch k, over several alternations of the two slots."""
+    name, B = "yolov4-tiny", 4
+    net = netutil.DkNet(gpu, netutil.cfg_path(name), weights[name], batch=B)
+    rng = np.random.default_rng(5)
+    sets = [rng.integers(0, 256, (B, net.h, net.w, net.c), dtype=np.uint8) for _ in range(3)]
+    heads = [i for i in range(net.n) if net.info(i)["type"] == O.YOLO]
+    ref = []
+    for f in sets:
+        net.predict_u8(f)
+        ref.append([net.output(i) for i in heads])
+    net.stage_u8(sets[0])
+    for k in range(6):
+        net.predict_staged()                 # batch k (asynchronous)
+        net.stage_u8(sets[(k + 1) % 3])      # batch k+1 into the other slot while k runs
+        for i, r in zip(heads, ref[k % 3]):
+            assert np.array_equal(net.output(i), r), "staged batch %d differs" % k
+    net.close()
+
+
 def test_properties_at_baseline_size(gpu, weights):
     """BASELINE config C3 (yolov4 608^2 b=16): batch-position invariance, eager ==
     graph replay, fusion on == off -- all bitwise, and item 0 == the b=1 golden run."""
