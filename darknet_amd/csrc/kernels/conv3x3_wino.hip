@@ -49,7 +49,7 @@
 #include "dk_internal.h"
 
 // diagnostic ablation builds (tools/build_ablate_wino.sh; results are garbage by construction):
-// bit 0 no input DMA, 1 no filter DMA, 2 no input transform / V writes
+// bit 0 no input DMA, 1 no filter DMA, 2 no input transform / V writes, 3 no wait for the DMA (exposed latency?)
 #ifndef DK_WABL
 #define DK_WABL 0
 #endif
@@ -135,9 +135,10 @@ __global__ void __launch_bounds__(256) conv3x3_wino_f32(const ConvArgs p)
 {
   constexpr int KMAX = wino_kmax(VW);
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* const Us = lds;                 // [3][W_STAGE]  transformed filters, LDS-DMA ring
-  float* const Vs = lds + 3 * W_STAGE;   // [2][W_STAGE]  transformed input, double-buffered
-  float* const Rs = lds + 5 * W_STAGE;   // [3][RAWF]     raw input rows, LDS-DMA ring: [4 ch][RS rows][Pw]
+  const int D = p.wino_ring;             // ring depth (3 or 4: what fits the 160 KB), prefetch distance D - 1 stages
+  float* const Us = lds;                       // [D][W_STAGE]  transformed filters, LDS-DMA ring
+  float* const Vs = lds + D * W_STAGE;         // [2][W_STAGE]  transformed input, double-buffered
+  float* const Rs = lds + (D + 2) * W_STAGE;   // [D][RAWF]     raw input rows, LDS-DMA ring: [4 ch][RS rows][Pw]
 
   int g, tile_m, tile_n;
   if (!conv_block_tile(p, g, tile_m, tile_n))
@@ -158,7 +159,7 @@ __global__ void __launch_bounds__(256) conv3x3_wino_f32(const ConvArgs p)
   const u32x4_t ur = make_rsrc(p.w, p.w_bytes);
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)lds);
   const unsigned u_lds = lds0 + (unsigned)(wave * 64) * 16u;                               // + slot * 16 KB + j * 4 KB
-  const unsigned r_lds = lds0 + (unsigned)(5 * W_STAGE) * 4u + (unsigned)(wave * 64 * VW) * 4u;   // + slot * RAWF * 4 + k * 256 * VW * 4
+  const unsigned r_lds = lds0 + (unsigned)((D + 2) * W_STAGE) * 4u + (unsigned)(wave * 64 * VW) * 4u;   // + slot * RAWF * 4 + k * 256 * VW * 4
 
   // ---- geometry of the strip: tile rows R0 .. Rlast (R = b * TH + ty), first tile column tx0 ----
   const int R0 = fdiv(n0, TW, p.inv_tiles_w);
@@ -215,13 +216,13 @@ __global__ void __launch_bounds__(256) conv3x3_wino_f32(const ConvArgs p)
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
   // zero the raw ring once (padding positions are never written again)
-  for (int i = tid; i < 3 * RAWF; i += 256) Rs[i] = 0.f;
+  for (int i = tid; i < D * RAWF; i += 256) Rs[i] = 0.f;
   barrier_lds();
 
   // LDS-DMA issue: raw rows of stage s into ring slot s % 3, filters of stage s into ring slot s % 3
   auto issue_raw = [&](int s) {
     const unsigned xo = (unsigned)s * stage_x_bytes;
-    const unsigned dst = r_lds + (unsigned)((s % 3) * RAWF) * 4u;
+    const unsigned dst = r_lds + (unsigned)((s % D) * RAWF) * 4u;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k)
       if (k < NK && !(DK_WABL & 1))
@@ -234,7 +235,7 @@ __global__ void __launch_bounds__(256) conv3x3_wino_f32(const ConvArgs p)
   };
   auto issue_u = [&](int s) {
     const unsigned uo = ubase + (unsigned)s * (unsigned)(W_STAGE * 4);
-    const unsigned dst = u_lds + (unsigned)((s % 3) * W_STAGE) * 4u;
+    const unsigned dst = u_lds + (unsigned)((s % D) * W_STAGE) * 4u;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (!(DK_WABL & 2))
@@ -298,11 +299,13 @@ __global__ void __launch_bounds__(256) conv3x3_wino_f32(const ConvArgs p)
     }
   };
 
-  // ---- prologue: raw(0), B(0), B(1) in flight; V(0) from raw(0) --------------------------------
+  // ---- prologue: raw(0), B(0) .. B(D-2) in flight; V(0) from raw(0) ----------------------------
   issue_raw(0);
   issue_bundle(0);
   issue_bundle(1);
-  wait_vmcnt_n(bundle_count(0) + bundle_count(1));
+  if (D > 3)
+    issue_bundle(2);
+  wait_vmcnt_n(bundle_count(0) + bundle_count(1) + (D > 3 ? bundle_count(2) : 0));
   barrier_lds();
   tslice(std::integral_constant<int, 0>(), Rs, Vs);
   tslice(std::integral_constant<int, 1>(), Rs, Vs);
@@ -317,12 +320,13 @@ __global__ void __launch_bounds__(256) conv3x3_wino_f32(const ConvArgs p)
   {
     // B(t) has landed for this wave; behind the barrier for every wave, and every wave has left
     // iteration t - 1 (V(t) complete; ring slots of U(t-1) and raw(t) free)
-    wait_vmcnt_n(bundle_count(t + 1));
+    if (!(DK_WABL & 8))
+      wait_vmcnt_n(bundle_count(t + 1) + (D > 3 ? bundle_count(t + 2) : 0));
     barrier_lds();
-    issue_bundle(t + 2);
-    const float2* const Ua = (const float2*)(Us + (t % 3) * W_STAGE) + wm * 64 + lh * 32 + l31;
+    issue_bundle(t + D - 1);
+    const float2* const Ua = (const float2*)(Us + (t % D) * W_STAGE) + wm * 64 + lh * 32 + l31;
     const float2* const Va = (const float2*)(Vs + (t & 1) * W_STAGE) + wn * 64 + lh * 32 + l31;
-    const float* const Rcur = Rs + ((t + 1) % 3) * RAWF;
+    const float* const Rcur = Rs + ((t + 1) % D) * RAWF;
     float* const Vnext = Vs + ((t + 1) & 1) * W_STAGE;
     // ---- 16 positions x 2 k-pairs, four positions at a time with their MFMAs interleaved; the
     // fragments of the next group are requested before the MFMAs of the current one are issued,
@@ -605,7 +609,17 @@ int dk_conv_wino_launch(ConvArgs a, int c, hipStream_t st)
   const long long nblk = conv_pick_partition(a, (size_t)a.w_bytes, WBM);
   if (drop_w)
     a.w_bytes = 0;
-  const int bytes = (5 * W_STAGE + 3 * o.nk * 256 * o.vw) * (int)sizeof(float);
+  // ring depth 3 (prefetch distance 2 stages).  DK_WINO_RING=4 takes a 4th slot where it fits the 160 KB:
+  // measured no gain (0.190 vs 0.184 ms on [128->128 76x76]) although skipping the DMA wait altogether is
+  // worth 7 % -- the rings are limited by LDS write bandwidth shared with the fragment reads, not by latency
+  const int raw_f = o.nk * 256 * o.vw;
+  a.wino_ring = 3;
+  {
+    static const int force = getenv("DK_WINO_RING") ? atoi(getenv("DK_WINO_RING")) : 0;
+    if (force == 4 && (6 * W_STAGE + 4 * raw_f) * (int)sizeof(float) <= 160 * 1024)
+      a.wino_ring = 4;
+  }
+  const int bytes = ((a.wino_ring + 2) * W_STAGE + a.wino_ring * raw_f) * (int)sizeof(float);
   void (*k)(const ConvArgs) = o.vw == 4 ? conv3x3_wino_f32<4, true> : (pair ? conv3x3_wino_f32<1, true> : conv3x3_wino_f32<1, false>);
   dk_set_max_dynamic_lds((const void*)k, bytes);
   hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), bytes, st, a);

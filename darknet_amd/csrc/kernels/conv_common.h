@@ -50,7 +50,7 @@ struct ConvArgs
   int tiles_w, tiles_hw;
   double inv_tiles_w, inv_tiles_hw;
   // ... raw-patch geometry: tile rows per image, column groups per staged row, rows per channel, loads per thread
-  int wino_th, wino_gp, wino_rs, wino_nk;
+  int wino_th, wino_gp, wino_rs, wino_nk, wino_ring;
   double inv_wino_th, inv_wino_gp, inv_wino_rsg;
 };
 
