@@ -77,6 +77,22 @@ inline void chan_split(int batch, int filters, int spatial, int* chunks, size_t*
   *chunks = (int)((n + *slice - 1) / *slice);
 }
 
+// The same for kernels that walk ONE (image, channel) plane per workgroup (contiguous memory: 16-byte
+// loads, no per-element index division): cps chunks per plane, `slice` elements (a multiple of 4) each;
+// grid = (cps * batch, filters).
+inline void plane_split(int batch, int filters, int spatial, int* cps, int* slice)
+{
+  const long long planes = (long long)batch * (filters > 0 ? filters : 1);
+  long long c = 2048 / (planes > 0 ? planes : 1);
+  if (c < 1) c = 1;
+  const long long maxc = ((long long)spatial + 2047) / 2048;  // at least ~2048 elements per workgroup
+  if (c > maxc) c = maxc;
+  int sl = (int)(((long long)spatial + c - 1) / c);
+  sl = (sl + 3) & ~3;
+  *slice = sl;
+  *cps = (spatial + sl - 1) / sl;
+}
+
 __device__ __forceinline__ double block_sum(double v, double* sh)
 {
 #pragma unroll
@@ -112,21 +128,32 @@ __device__ __forceinline__ size_t chan_index(size_t t, int f, int filters, int s
 // (the reference's N-1 denominator, src/blas.c:186; evaluated in double, so the
 // one-pass form loses nothing), rolling statistics .9/.1.
 __global__ void __launch_bounds__(RT) bn_partial_kernel(const float* __restrict__ x, int batch,
-    int filters, int spatial, size_t slice, double* __restrict__ scratch)
+    int filters, int spatial, int cps, int slice, double* __restrict__ scratch)
 {
   __shared__ double sh[RT / 64];
   const int f = blockIdx.y;
-  const size_t n = (size_t)batch * spatial;
-  const size_t t0 = blockIdx.x * slice;
-  size_t t1 = t0 + slice;
-  if (t1 > n)
-    t1 = n;
+  const int b = blockIdx.x / cps, ch = blockIdx.x - b * cps;
+  const int i0 = ch * slice;
+  const int i1 = (i0 + slice < spatial) ? i0 + slice : spatial;
+  const float* const px = x + ((size_t)b * filters + f) * spatial;
   double s = 0, q = 0;
-  for (size_t t = t0 + threadIdx.x; t < t1; t += RT)
+  if ((spatial & 3) == 0 && (((uintptr_t)x) & 15) == 0)
   {
-    const double v = x[chan_index(t, f, filters, spatial)];
-    s += v;
-    q += v * v;
+    for (int i = i0 + 4 * (int)threadIdx.x; i < i1; i += 4 * RT)
+    {
+      const float4 v = *(const float4*)(px + i);
+      s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+      q += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+  }
+  else
+  {
+    for (int i = i0 + (int)threadIdx.x; i < i1; i += RT)
+    {
+      const double v = px[i];
+      s += v;
+      q += v * v;
+    }
   }
   s = block_sum(s, sh);
   q = block_sum(q, sh);
@@ -165,27 +192,61 @@ __global__ void bn_finalize_kernel(double* __restrict__ scratch, int batch, int 
 }
 
 // normalize_cpu (eps 1e-6) + scale_bias + add_bias + activation, one pass.
+// grid (batch*filters, chunks): one (image, channel) plane per blockIdx.x -> channel constants are
+// scalars, no per-element division, 16-byte accesses when the planes allow it.
+__device__ __forceinline__ float bn_apply_one(float v, float m, float div, float sc, float bi, int act,
+    float* xn_out, float* pre_out)
+{
+  float xn = (v - m) / div;
+  *xn_out = xn;
+  xn = xn * sc;
+  xn = xn + bi;
+  *pre_out = xn;
+  return dk_activate(xn, act);
+}
+
 __global__ void bn_apply_kernel(const float* __restrict__ raw, float* __restrict__ x_save,
     float* __restrict__ x_norm, float* __restrict__ act_in, float* __restrict__ out,
     const float* __restrict__ mean, const float* __restrict__ variance,
     const float* __restrict__ scales, const float* __restrict__ biases, int filters, int spatial,
-    size_t total, int act)
+    int act, int vec)
 {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
-       i += (size_t)gridDim.x * blockDim.x)
+  const int plane = blockIdx.x;
+  const int f = plane % filters;
+  const float m = mean[f], div = sqrtf(variance[f] + .000001f), sc = scales[f], bi = biases[f];
+  const size_t base = (size_t)plane * spatial;
+  if (vec)
   {
-    const int f = (int)((i / spatial) % filters);
-    const float v = raw[i];
+    for (int i = 4 * (blockIdx.y * blockDim.x + threadIdx.x); i < spatial; i += 4 * gridDim.y * blockDim.x)
+    {
+      const float4 v = *(const float4*)(raw + base + i);
+      float4 xn, pre, o;
+      o.x = bn_apply_one(v.x, m, div, sc, bi, act, &xn.x, &pre.x);
+      o.y = bn_apply_one(v.y, m, div, sc, bi, act, &xn.y, &pre.y);
+      o.z = bn_apply_one(v.z, m, div, sc, bi, act, &xn.z, &pre.z);
+      o.w = bn_apply_one(v.w, m, div, sc, bi, act, &xn.w, &pre.w);
+      if (x_save)
+        *(float4*)(x_save + base + i) = v;
+      if (x_norm)
+        *(float4*)(x_norm + base + i) = xn;
+      if (act_in)
+        *(float4*)(act_in + base + i) = pre;
+      *(float4*)(out + base + i) = o;
+    }
+    return;
+  }
+  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < spatial; i += gridDim.y * blockDim.x)
+  {
+    const float v = raw[base + i];
+    float xn, pre;
+    const float o = bn_apply_one(v, m, div, sc, bi, act, &xn, &pre);
     if (x_save)
-      x_save[i] = v;
-    float xn = (v - mean[f]) / (sqrtf(variance[f] + .000001f));
+      x_save[base + i] = v;
     if (x_norm)
-      x_norm[i] = xn;
-    xn = xn * scales[f];
-    xn = xn + biases[f];
+      x_norm[base + i] = xn;
     if (act_in)
-      act_in[i] = xn;
-    out[i] = dk_activate(xn, act);
+      act_in[base + i] = pre;
+    out[base + i] = o;
   }
 }
 
@@ -360,28 +421,40 @@ __device__ __forceinline__ BnRecompute bn_recompute(float x, float delta, float 
 __global__ void __launch_bounds__(RT) bn_act_partial_kernel(const float* __restrict__ delta,
     const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ variance,
     const float* __restrict__ scales, const float* __restrict__ biases, int batch, int filters,
-    int spatial, size_t slice, double* __restrict__ scratch, int act)
+    int spatial, int cps, int slice, double* __restrict__ scratch, int act)
 {
   __shared__ double sh[RT / 64];
   const int f = blockIdx.y;
-  const size_t n = (size_t)batch * spatial;
-  const size_t t0 = blockIdx.x * slice;
-  size_t t1 = t0 + slice;
-  if (t1 > n)
-    t1 = n;
+  const int b = blockIdx.x / cps, ch = blockIdx.x - b * cps;
+  const int i0 = ch * slice;
+  const int i1 = (i0 + slice < spatial) ? i0 + slice : spatial;
+  const size_t base = ((size_t)b * filters + f) * spatial;
   double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
   const float sc = scales[f], bi = biases[f], m = mean[f];
   const float div = sqrtf(variance[f] + .000001f);
-  for (size_t t = t0 + threadIdx.x; t < t1; t += RT)
-  {
-    const size_t idx = chan_index(t, f, filters, spatial);
-    const float xv = x[idx];
-    const BnRecompute r = bn_recompute(xv, delta[idx], m, div, sc, bi, act);
+  auto one = [&](float xv, float dv) {
+    const BnRecompute r = bn_recompute(xv, dv, m, div, sc, bi, act);
     s0 += r.d;
     s1 += r.d * r.xn;
     const float ds = r.d * sc;
     s2 += ds;
     s3 += ds * (xv - m);
+  };
+  if ((spatial & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)delta)) & 15) == 0)
+  {
+    for (int i = i0 + 4 * (int)threadIdx.x; i < i1; i += 4 * RT)
+    {
+      const float4 xv = *(const float4*)(x + base + i);
+      const float4 dv = *(const float4*)(delta + base + i);
+      one(xv.x, dv.x);
+      one(xv.y, dv.y);
+      one(xv.z, dv.z);
+      one(xv.w, dv.w);
+    }
+  }
+  else
+  {
+    for (int i = i0 + (int)threadIdx.x; i < i1; i += RT) one(x[base + i], delta[base + i]);
   }
   s0 = block_sum(s0, sh);
   s1 = block_sum(s1, sh);
@@ -396,14 +469,14 @@ __global__ void __launch_bounds__(RT) bn_act_partial_kernel(const float* __restr
   }
 }
 
-// grid (chunks, batch*filters): one (image, channel) plane per blockIdx.y -> no per-element division
+// grid (batch*filters, chunks): one (image, channel) plane per blockIdx.x -> no per-element division
 __global__ void bn_act_delta_kernel(float* __restrict__ delta, const float* __restrict__ x,
     const float* __restrict__ mean, const float* __restrict__ variance,
     const float* __restrict__ mean_delta, const float* __restrict__ variance_delta,
     const float* __restrict__ scales, const float* __restrict__ biases, int batch, int filters,
     int spatial, int act)
 {
-  const int plane = blockIdx.y;
+  const int plane = blockIdx.x;
   const int f = plane % filters;
   const int nb = spatial * batch;
   const float sc = scales[f], bi = biases[f], m = mean[f], var = variance[f];
@@ -411,7 +484,7 @@ __global__ void bn_act_delta_kernel(float* __restrict__ delta, const float* __re
   const float vd = variance_delta[f], md = mean_delta[f];
   float* dp = delta + (size_t)plane * spatial;
   const float* xp = x + (size_t)plane * spatial;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < spatial; i += gridDim.x * blockDim.x)
+  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < spatial; i += gridDim.y * blockDim.x)
   {
     const float xv = xp[i];
     const BnRecompute r = bn_recompute(xv, dp[i], m, div, sc, bi, act);
@@ -562,18 +635,25 @@ extern "C" int dk_bn_forward_train(const float* raw, float* x_save, float* x_nor
   {
     hipStream_t st = S(stream);
     double* scratch = chan_scratch(filters, st);
-    int chunks;
-    size_t slice;
-    chan_split(batch, filters, spatial, &chunks, &slice);
-    hipLaunchKernelGGL(bn_partial_kernel, dim3(chunks, filters), dim3(RT), 0, st, raw, batch,
-        filters, spatial, slice, scratch);
+    int cps, slice;
+    plane_split(batch, filters, spatial, &cps, &slice);
+    hipLaunchKernelGGL(bn_partial_kernel, dim3(cps * batch, filters), dim3(RT), 0, st, raw, batch,
+        filters, spatial, cps, slice, scratch);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((filters + 255) / 256), dim3(256), 0, st, scratch,
         batch, filters, spatial, mean, variance, rolling_mean, rolling_variance);
     CHECK_HIP(hipPeekAtLastError());
   }
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total)), dim3(256), 0, S(stream), raw,
-      train ? x_save : nullptr, train ? x_norm : nullptr, act_in, out, train ? mean : rolling_mean,
-      train ? variance : rolling_variance, scales, biases, filters, spatial, total, activation);
+  {
+    float* const xs = train ? x_save : nullptr;
+    float* const xn = train ? x_norm : nullptr;
+    const uintptr_t al = (uintptr_t)raw | (uintptr_t)out | (uintptr_t)xs | (uintptr_t)xn | (uintptr_t)act_in;
+    const int vec = ((spatial & 3) == 0 && (al & 15) == 0) ? 1 : 0;
+    int gx = (spatial + (vec ? 4095 : 1023)) / (vec ? 4096 : 1024);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(batch * filters, gx), dim3(256), 0, S(stream), raw, xs, xn, act_in, out,
+        train ? mean : rolling_mean, train ? variance : rolling_variance, scales, biases, filters, spatial,
+        activation, vec);
+  }
   CHECK_HIP(hipPeekAtLastError());
   return 0;
 }
@@ -649,16 +729,15 @@ extern "C" int dk_bn_act_backward(float* delta, const float* x, const float* mea
   if (activation == DK_MISH && dk_fast_mish_enabled())
     activation |= DK_ACT_FAST;
   double* scratch = chan_scratch(filters, st);
-  int chunks;
-  size_t slice;
-  chan_split(batch, filters, spatial, &chunks, &slice);
-  hipLaunchKernelGGL(bn_act_partial_kernel, dim3(chunks, filters), dim3(RT), 0, st, delta, x, mean,
-      variance, scales, biases, batch, filters, spatial, slice, scratch, activation);
+  int cps, slice;
+  plane_split(batch, filters, spatial, &cps, &slice);
+  hipLaunchKernelGGL(bn_act_partial_kernel, dim3(cps * batch, filters), dim3(RT), 0, st, delta, x, mean,
+      variance, scales, biases, batch, filters, spatial, cps, slice, scratch, activation);
   hipLaunchKernelGGL(chan_finalize_kernel, dim3((filters + 255) / 256), dim3(256), 0, st, scratch,
       variance, filters, bias_updates, scale_updates, mean_delta, variance_delta, 1);
   int gx = (spatial + 1023) / 1024;
   if (gx > 64) gx = 64;
-  hipLaunchKernelGGL(bn_act_delta_kernel, dim3(gx, batch * filters), dim3(256), 0, st, delta, x, mean,
+  hipLaunchKernelGGL(bn_act_delta_kernel, dim3(batch * filters, gx), dim3(256), 0, st, delta, x, mean,
       variance, mean_delta, variance_delta, scales, biases, batch, filters, spatial, activation);
   CHECK_HIP(hipPeekAtLastError());
   return 0;
