@@ -209,6 +209,56 @@ def test_big_nets_b1_vs_golden(gpu, weights, name):
     net.close()
 
 
+def test_predict_on_unplanned_nets(gpu, tmp_path):
+    """NetworkPredict on nets that never went through the inference plan: (1) LoadNetwork(train=true) -- BN not
+    folded, rolling statistics -- and (2) the public ParseNetworkCfg + LoadWeights + FuseConvBatchNorm path.
+    Both must run eagerly (no allocation inside a stream capture) and match the oracle."""
+    name = "yolov4-tiny"
+    L = gpu.lib()
+    cfg = str(tmp_path / "t.cfg")
+    open(cfg, "w").write(open(netutil.cfg_path(name)).read().replace("batch=64", "batch=2").replace("subdivisions=1", "subdivisions=1"))
+    w = str(tmp_path / "w.weights")
+    netutil.synth_weights_for(gpu, name, w)
+    x = synth.make_input(2, 3, 416, 416, seed=9)
+    onet = O.load_network(cfg, w, batch=2)
+    O.forward(onet, x)
+    want = {i: l.output for i, l in enumerate(onet.layers) if l.type == O.YOLO}
+    # (1) train load, then predict twice (the second call is where a graph would be captured)
+    net = netutil.DkNet(gpu, cfg, w, train=True)
+    assert net.batch == 2
+    for rep in range(2):
+        net.predict(x)
+        for i, o in want.items():
+            util.assert_close(net.output(i), o.reshape(2, -1), "train-loaded net, head %d (run %d)" % (i, rep), rel=2e-4, atol_rms=3e-5)
+    net.close()
+    # (2) parse + load + fuse by hand
+    L.ParseNetworkCfg.argtypes = [C.c_void_p, C.c_char_p, C.c_bool]
+    L.ParseNetworkCfg.restype = C.c_bool
+    L.LoadWeights.argtypes = [C.c_void_p, C.c_char_p]
+    L.LoadWeights.restype = C.c_bool
+    L.FuseConvBatchNorm.argtypes = [C.c_void_p]
+    L.FuseConvBatchNorm.restype = None
+    p = L.DkNetworkCreate()
+    assert L.ParseNetworkCfg(p, cfg.encode(), False)
+    assert L.LoadWeights(p, w.encode())
+    L.FuseConvBatchNorm(p)
+    a = (C.c_int * 8)()
+    L.DkNetworkInfo(p, a)
+    nb = a[1]
+    xin = np.ascontiguousarray(x[:nb])
+    for rep in range(2):
+        L.NetworkPredict(p, xin.ctypes.data)
+        for i, o in want.items():
+            f = (C.c_int * 24)()
+            L.DkLayerInfo(p, i, f)
+            n = nb * o[0].size
+            out = np.empty(n, np.float32)
+            assert L.DkLayerOutput(p, i, out.ctypes.data, n) == 0
+            util.assert_close(out.reshape(nb, -1), o.reshape(2, -1)[:nb], "manual path, head %d (run %d)" % (i, rep))
+    L.FreeNetwork(p)
+    L.DkNetworkDestroy(p)
+
+
 def test_staged_u8_input_double_buffer(gpu, weights):
     """DkNetworkStageU8 / DkNetworkPredictStaged (the double-buffered input step): staging batch k+1 while the
     forward of batch k is in flight must not disturb batch k, over several alternations of the two slots."""

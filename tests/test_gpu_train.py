@@ -470,6 +470,54 @@ def test_split_train_step_equals_train_network_datum(gpu, tmp_path):
     a.close(); b.close()
 
 
+def test_stopbackward_split_step_equals_unsplit(gpu, tmp_path):
+    """`stopbackward=1` (network_kernels.cu:140-143 ends the backward sweep for good): the split step must
+    not resume the sweep in the next DkBackwardRange segment -- gradients below the stop layer stay exactly what
+    the unsplit step leaves there (zero), above it they agree."""
+    from darknet_amd.train_dist import bucket_segments
+    g, cfg, wpath, x = train_fixture(tmp_path)
+    txt = open(cfg).read()
+    # stop the sweep at the 8th conv section (layer 9 of yolov4-tiny's backbone)
+    parts = txt.split("[convolutional]\n")
+    assert len(parts) > 10
+    parts[8] = "stopbackward=1\n" + parts[8]
+    cfg2 = str(tmp_path / "stop.cfg")
+    open(cfg2, "w").write("[convolutional]\n".join(parts))
+    L = gpu.lib()
+    for fn, at, rt in (("TrainNetworkDatum", [VP, VP, VP], C.c_float), ("DkTrainForward", [VP, VP, VP], None),
+                       ("DkBackwardRange", [VP, C.c_int, C.c_int], None), ("DkTrainFinish", [VP], C.c_float),
+                       ("DkGradBucketOffset", [VP, C.c_int], C.c_size_t),
+                       ("DkLayerPull", [VP, C.c_int, C.c_int, VP, C.c_size_t], C.c_long)):
+        getattr(L, fn).argtypes = at
+        getattr(L, fn).restype = rt
+    truth = np.ascontiguousarray(g["truth"])
+    xin = np.ascontiguousarray(x)
+    a = netutil.DkNet(gpu, cfg2, wpath, train=True)
+    cost_a = L.TrainNetworkDatum(a.p, xin.ctypes.data, truth.ctypes.data)
+    b = netutil.DkNet(gpu, cfg2, wpath, train=True)
+    offs = [L.DkGradBucketOffset(b.p, i) for i in range(b.n + 1)]
+    convs = [i for i in range(b.n) if offs[i + 1] > offs[i]]
+    segs = bucket_segments(convs, [offs[i + 1] - offs[i] for i in convs], b.n, 4)
+    L.DkTrainForward(b.p, xin.ctypes.data, truth.ctypes.data)
+    for hi, lo, off, cnt in segs:
+        L.DkBackwardRange(b.p, hi, lo)
+    cost_b = L.DkTrainFinish(b.p)
+    assert cost_a == cost_b
+    zero_layers = 0
+    for i in convs:
+        f = a.info(i)
+        ga, gb = np.empty(f["nweights"], np.float32), np.empty(f["nweights"], np.float32)
+        assert L.DkLayerPull(a.p, i, 7, ga.ctypes.data, ga.size) == ga.size
+        assert L.DkLayerPull(b.p, i, 7, gb.ctypes.data, gb.size) == gb.size
+        if not ga.any():
+            zero_layers += 1
+            assert not gb.any(), "layer %d below the stopbackward layer received a gradient in the split step" % i
+        else:
+            util.assert_close(gb, ga, "layer %d gradient" % i, rel=1e-4, atol_rms=1e-5)
+    assert zero_layers >= 3, "the stop did not cut any layer off (fixture does not exercise stopbackward)"
+    a.close(); b.close()
+
+
 def test_train_networks_c_entry_equals_subdivisions(gpu, tmp_path):
     """The C-level data-parallel entry (TrainNetworks, csrc/host/multigpu.cpp; reference signature
     network_kernels.cu:446-484): two replicas in one Network array, one host thread each, gradient
