@@ -665,15 +665,29 @@ float* NetworkPredict(Network* net, float* input) { return NetworkPredictGpu(net
 
 // the input step before the path.  The frames cross PCIe as bytes (4x fewer
 // than floats) and Mat2Image's arithmetic runs on the device.
+static void stage_frames(Network* net, const unsigned char* frames_hwc, int src_w, int src_h, size_t row_step, int swap_rb);
+
 void DkNetworkStageU8(Network* net, const unsigned char* frames_hwc, size_t row_step)
+{
+  stage_frames(net, frames_hwc, 0, 0, row_step, 0);
+}
+
+void DkNetworkStageFrames(Network* net, const unsigned char* frames_hwc, int src_w, int src_h, size_t row_step, int swap_rb)
+{
+  if (src_w < 1 || src_h < 1)
+    error("DkNetworkStageFrames: invalid frame size");
+  stage_frames(net, frames_hwc, src_w, src_h, row_step, swap_rb);
+}
+
+static void stage_frames(Network* net, const unsigned char* frames_hwc, int src_w, int src_h, size_t row_step, int swap_rb)
 {
   if (net->gpu_index < 0)
     error("DkNetworkStageU8: no HIP device (this library has no CPU fallback)");
   if (net->gpu_index != cuda_get_device())
     cuda_set_device(net->gpu_index);
-  if (row_step < (size_t)net->w * net->c)
+  if (row_step < (size_t)(src_w ? src_w : net->w) * net->c)
     error("DkNetworkStageU8: row_step smaller than one row");
-  const size_t bytes = row_step * net->h * net->batch;
+  const size_t bytes = row_step * (src_h ? src_h : net->h) * net->batch;
   if (net->u8_bytes < bytes)
   {
     NetworkSync(net);
@@ -712,6 +726,9 @@ void DkNetworkStageU8(Network* net, const unsigned char* frames_hwc, size_t row_
   CHECK_HIP(hipEventRecord((hipEvent_t)net->u8_h2d_ev[slot], cs));
   net->u8_staged = slot + 1;
   net->u8_row_step = row_step;
+  net->u8_src_w = src_w;
+  net->u8_src_h = src_h;
+  net->u8_swap_rb = swap_rb;
   net->u8_next = slot ^ 1;
 }
 
@@ -727,8 +744,14 @@ void DkNetworkPredictStaged(Network* net)
   hipStream_t st = get_cuda_stream();
   // stream order already puts the conversion behind the previous forward's reads of the input tensor
   CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)net->u8_h2d_ev[slot], 0));
-  if (dk_image_u8_to_chw(slot ? net->u8_gpu2 : net->u8_gpu, net->input_state_gpu, net->batch, net->w, net->h, net->c,
-          net->u8_row_step, st))
+  const unsigned char* const dev = slot ? net->u8_gpu2 : net->u8_gpu;
+  if (net->u8_src_w > 0)
+  {
+    if (dk_image_resize_u8_to_chw(dev, net->u8_src_w, net->u8_src_h, net->u8_row_step, net->input_state_gpu, net->batch,
+            net->w, net->h, net->c, net->u8_swap_rb, st))
+      error("dk_image_resize_u8_to_chw failed");
+  }
+  else if (dk_image_u8_to_chw(dev, net->input_state_gpu, net->batch, net->w, net->h, net->c, net->u8_row_step, st))
     error("dk_image_u8_to_chw failed");
   CHECK_HIP(hipEventRecord((hipEvent_t)net->u8_conv_ev[slot], st));
   net->u8_conv_pending[slot] = 1;

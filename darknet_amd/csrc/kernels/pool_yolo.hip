@@ -194,7 +194,88 @@ __global__ void u8_hwc_to_chw_kernel(const unsigned char* __restrict__ src, floa
     dst[id] = src[b * image_bytes + (size_t)y * step + (size_t)x * c + k] / 255.0f;
   }
 }
+// cv::resize(src, dst, Size(w, h)) with the default INTER_LINEAR on 8-bit interleaved frames, then (optionally)
+// cv::cvtColor(RGB2BGR), then Mat2Image -- the input step of the reference's ProcImage (src/yolo_core.cpp:104-112)
+// in ONE pass.  The resize is OpenCV's generic fixed-point path (modules/imgproc/src/resize.cpp, 4.x:
+// resizeGeneric_ with HResizeLinear / VResizeLinear for uchar): 11-bit coefficients
+// ialpha = cvRound((1-fx)*2048), cvRound(fx*2048) with fx = (float)((dx+0.5)*scale-0.5) - floor, left/right columns
+// clamped with fx = 0, rows clamped; dst = (((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2 with
+// S = s[sx]*a0 + s[sx+1]*a1; an exact 2x shrink takes OpenCV's area shortcut (sum of the 2x2 block + 2) >> 2.
+// OpenCV is not in this image and the reference ships no frames, so this restatement is checked against
+// oracle/orc_resize.py only ("parity unpinned" against an OpenCV build; IPP builds differ anyway).
+__global__ void resize_u8_to_chw_kernel(const unsigned char* __restrict__ src, int sw, int sh, size_t sstep,
+    size_t simage, float* __restrict__ dst, int w, int h, int c, int swap_rb, double scale_x, double scale_y,
+    int area2, size_t total)
+{
+  for (size_t id = blockIdx.x * (size_t)blockDim.x + threadIdx.x; id < total; id += (size_t)gridDim.x * blockDim.x)
+  {
+    const int dx = (int)(id % w);
+    size_t t = id / w;
+    const int dy = (int)(t % h);
+    const size_t b = t / h;
+    const unsigned char* const img = src + b * simage;
+    int out[4];
+    if (area2)
+    {
+      const unsigned char* r0 = img + (size_t)(2 * dy) * sstep + (size_t)(2 * dx) * c;
+      const unsigned char* r1 = r0 + sstep;
+      for (int k = 0; k < c; ++k) out[k] = (r0[k] + r0[c + k] + r1[k] + r1[c + k] + 2) >> 2;
+    }
+    else
+    {
+      float fx = (float)(((double)dx + 0.5) * scale_x - 0.5);
+      int sx = (int)floorf(fx);
+      fx -= (float)sx;
+      if (sx < 0) { fx = 0.f; sx = 0; }
+      if (sx >= sw - 1) { fx = 0.f; sx = sw - 1; }
+      const int sx1 = (sx + 1 < sw) ? sx + 1 : sw - 1;
+      const int a0 = __float2int_rn((1.f - fx) * 2048.f), a1 = __float2int_rn(fx * 2048.f);
+      float fy = (float)(((double)dy + 0.5) * scale_y - 0.5);
+      const int sy = (int)floorf(fy);
+      fy -= (float)sy;
+      const int b0 = __float2int_rn((1.f - fy) * 2048.f), b1 = __float2int_rn(fy * 2048.f);
+      const int y0 = sy < 0 ? 0 : (sy > sh - 1 ? sh - 1 : sy);
+      const int y1 = sy + 1 < 0 ? 0 : (sy + 1 > sh - 1 ? sh - 1 : sy + 1);
+      const unsigned char* r0 = img + (size_t)y0 * sstep;
+      const unsigned char* r1 = img + (size_t)y1 * sstep;
+      for (int k = 0; k < c; ++k)
+      {
+        const int S0 = r0[sx * c + k] * a0 + r0[sx1 * c + k] * a1;
+        const int S1 = r1[sx * c + k] * a0 + r1[sx1 * c + k] * a1;
+        int v = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;
+        out[k] = v < 0 ? 0 : (v > 255 ? 255 : v);
+      }
+    }
+    const size_t plane = (size_t)w * h;
+    float* const o = dst + b * plane * c + (size_t)dy * w + dx;
+    for (int k = 0; k < c; ++k)
+    {
+      const int kk = (swap_rb && c >= 3 && k < 3) ? 2 - k : k;   // cvtColor(RGB2BGR) swaps channels 0 and 2
+      o[(size_t)kk * plane] = (float)out[k] / 255.0f;
+    }
+  }
+}
 }  // namespace
+
+extern "C" int dk_image_resize_u8_to_chw(const unsigned char* src_hwc, int src_w, int src_h, size_t src_row_step,
+    float* chw, int batch, int w, int h, int c, int swap_rb, void* stream)
+{
+  if (!src_hwc || !chw || c < 1 || c > 4 || src_w < 1 || src_h < 1 || w < 1 || h < 1 || src_row_step < (size_t)src_w * c)
+  {
+    fprintf(stderr, "dk_image_resize_u8_to_chw: invalid arguments\n");
+    return 1;
+  }
+  const size_t total = (size_t)batch * h * w;
+  if (total == 0)
+    return 0;
+  // cv::resize: inv_scale = dsize / ssize, scale = 1 / inv_scale (resize.cpp)
+  const double scale_x = 1.0 / ((double)w / (double)src_w), scale_y = 1.0 / ((double)h / (double)src_h);
+  const int area2 = (src_w == 2 * w && src_h == 2 * h) ? 1 : 0;
+  hipLaunchKernelGGL(resize_u8_to_chw_kernel, dim3(grid_for(total)), dim3(256), 0, S(stream), src_hwc, src_w, src_h,
+      src_row_step, src_row_step * src_h, chw, w, h, c, swap_rb, scale_x, scale_y, area2, total);
+  CHECK_HIP(hipPeekAtLastError());
+  return 0;
+}
 
 extern "C" int dk_yolo_compact(const float* decoded, int batch, int lw, int lh, int n_anchors,
     int classes, float thresh, int tag, float* records, int* counter, int cap, void* stream)

@@ -140,6 +140,11 @@ DK_API int dk_nms_records(float* records, int count, int classes, const DkYoloHe
  * already in device memory: chw[b][k][y][x] = hwc[b][y*row_step + x*c + k] / 255.0f. */
 DK_API int dk_image_u8_to_chw(const unsigned char* hwc, float* chw, int batch, int w, int h, int c,
     size_t row_step, void* stream);
+/* cv::resize (INTER_LINEAR, 8-bit, OpenCV's fixed-point arithmetic) + optional RGB<->BGR swap + Mat2Image in one
+ * pass: the whole input step of the reference's ProcImage (src/yolo_core.cpp:104-112).  src: batch frames of
+ * src_h rows of src_row_step bytes (interleaved, c channels); chw: [batch][c][h][w] floats in [0, 1]. */
+DK_API int dk_image_resize_u8_to_chw(const unsigned char* src_hwc, int src_w, int src_h, size_t src_row_step,
+    float* chw, int batch, int w, int h, int c, int swap_rb, void* stream);
 
 /* ForwardYoloLayerGpu decode, src/yolo_layer.cpp:836-853, fused into one
  * launch: copy; logistic on x,y then v*scale_x_y - 0.5*(scale_x_y-1);

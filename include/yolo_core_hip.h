@@ -299,6 +299,7 @@ struct Network
   int u8_conv_pending[2];
   int u8_next, u8_staged; /* slot the next stage call fills; slot staged and not yet consumed (-1: none) + 1 */
   size_t u8_row_step;
+  int u8_src_w, u8_src_h, u8_swap_rb; /* staged frames at another resolution (DkNetworkStageFrames): 0 = network size */
   float* delta_arena_gpu; /* train: every layer's delta_gpu lives in this one allocation (one memset per step) */
   size_t delta_arena_size;
   float* grad_bucket;    /* caller-owned contiguous gradient bucket (DkAttachGradBucket), or NULL */
@@ -511,6 +512,11 @@ LIB_API void DkNetworkPredictU8(Network* net, const unsigned char* frames_hwc, s
  * forward pass that is running); DkNetworkPredictStaged converts the staged frames on the device and runs the
  * forward.  DkNetworkPredictU8 == Stage + PredictStaged. */
 LIB_API void DkNetworkStageU8(Network* net, const unsigned char* frames_hwc, size_t row_step);
+/* Frames at ANY resolution: cv::resize(INTER_LINEAR) [+ cvtColor(RGB2BGR) when swap_rb] + Mat2Image happen on the
+ * device in one kernel (dk_image_resize_u8_to_chw) when DkNetworkPredictStaged consumes them: the whole input step
+ * of the reference's ProcImage (src/yolo_core.cpp:104-112). */
+LIB_API void DkNetworkStageFrames(Network* net, const unsigned char* frames_hwc, int src_w, int src_h, size_t row_step,
+    int swap_rb);
 LIB_API void DkNetworkPredictStaged(Network* net);
 LIB_API float* DkLayerOutputGpu(Network* net, int i);
 LIB_API float* DkLayerHostPtr(Network* net, int i, int which); /* 1 weights 2 biases 3 scales 4 mean 5 var */

@@ -259,6 +259,51 @@ def test_predict_on_unplanned_nets(gpu, tmp_path):
     L.DkNetworkDestroy(p)
 
 
+@pytest.mark.parametrize("case", [(640, 480, 416, 416, 3, 1), (832, 832, 416, 416, 3, 0), (301, 177, 608, 608, 3, 1),
+                                  (416, 416, 416, 416, 3, 0), (1279, 721, 320, 352, 1, 0)])
+def test_device_resize_to_chw_vs_oracle(gpu, case):
+    """SURVEY 8f-2, the resize in front of Mat2Image (src/yolo_core.cpp:104-112): cv::resize INTER_LINEAR (8-bit
+    fixed point) + RGB<->BGR swap + /255 planar floats in one kernel, bit-exact against oracle/orc_resize.py
+    (OpenCV itself is absent: that restatement is "parity unpinned", see its header)."""
+    from oracle import orc_resize
+    sw, sh, w, h, c, swap = case
+    L = gpu.lib()
+    L.dk_image_resize_u8_to_chw.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]
+    L.dk_image_resize_u8_to_chw.restype = C.c_int
+    rng = np.random.default_rng(sw * 7 + sh)
+    B, step = 2, sw * c + 5          # padded rows
+    frames = rng.integers(0, 256, (B, sh, step), dtype=np.uint8)
+    want = orc_resize.resize_u8_to_chw(frames[:, :, :sw * c].reshape(B, sh, sw, c), w, h, bool(swap))
+    src = gpu.DeviceArray(np.frombuffer(np.pad(frames.reshape(-1), (0, (-frames.size) % 4)).tobytes(), np.int32), dtype=np.int32)
+    dst = gpu.DeviceArray(n=B * c * h * w)
+    assert L.dk_image_resize_u8_to_chw(src.ptr, sw, sh, step, dst.ptr, B, w, h, c, swap, None) == 0
+    got = dst.numpy().reshape(B, c, h, w)
+    assert np.array_equal(got, want), "device resize differs: %d of %d elements, max |d| %g" % (
+        (got != want).sum(), got.size, np.abs(got - want).max())
+
+
+def test_staged_frames_resize_predict(gpu, weights):
+    """DkNetworkStageFrames + DkNetworkPredictStaged: frames at camera resolution in, heads == the heads of the
+    float path fed with the oracle's resized input."""
+    from oracle import orc_resize
+    name, B = "yolov4-tiny", 2
+    L = gpu.lib()
+    L.DkNetworkStageFrames.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int]
+    L.DkNetworkStageFrames.restype = None
+    net = netutil.DkNet(gpu, netutil.cfg_path(name), weights[name], batch=B)
+    rng = np.random.default_rng(3)
+    frames = rng.integers(0, 256, (B, 480, 640, 3), dtype=np.uint8)
+    x = orc_resize.resize_u8_to_chw(frames, net.w, net.h, True)
+    net.predict(x)
+    heads = [i for i in range(net.n) if net.info(i)["type"] == O.YOLO]
+    ref = [net.output(i) for i in heads]
+    L.DkNetworkStageFrames(net.p, frames.ctypes.data, 640, 480, 640 * 3, 1)
+    net.predict_staged()
+    for i, r in zip(heads, ref):
+        assert np.array_equal(net.output(i), r), "frames path differs from the float path"
+    net.close()
+
+
 def test_staged_u8_input_double_buffer(gpu, weights):
     """DkNetworkStageU8 / DkNetworkPredictStaged (the double-buffered input step): staging batch k+1 while the
     forward of batch k is in flight must not disturb batch k, over several alternations of the two slots."""
