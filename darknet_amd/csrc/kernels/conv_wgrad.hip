@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "dark_hip.h"
 #include "dk_kernels.h"
@@ -333,7 +334,8 @@ extern "C" int dk_conv_backward_weights(const DkConvDesc* d, const float* x, con
     a.groups = d->groups;
     const int nstages = (a.N + NC - 1) / NC;
     const long long tiles = (long long)a.tiles_m * a.tiles_k * d->groups;
-    long long want = (1024 + tiles - 1) / tiles;  // ~4 workgroups per CU in total
+    static const long long target = getenv("DK_WGRAD_BLOCKS") ? atoll(getenv("DK_WGRAD_BLOCKS")) : 1024;
+    long long want = (target + tiles - 1) / tiles;  // ~4 workgroups per CU in total
     if (want < 1) want = 1;
     if (want > nstages) want = nstages;
     a.stages_per_split = (int)((nstages + want - 1) / want);
