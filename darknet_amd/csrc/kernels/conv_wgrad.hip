@@ -46,7 +46,9 @@ struct WgradArgs
 };
 
 constexpr unsigned OOB = 0x80000000u;
-constexpr int NC = 32, LS = NC + 1, T = 256;
+// LS = 34: rows 8-byte aligned, and 32 consecutive rows read with ds_read_b64 hit 32 distinct bank pairs
+// (34 m mod 64 = 2 (17 m mod 32), a bijection), so a lane fetches TWO contraction steps per LDS read
+constexpr int NC = 32, LS = NC + 2, T = 256;
 
 __device__ __forceinline__ float ld_buf(__amdgpu_buffer_rsrc_t r, unsigned byte_off)
 {
@@ -194,8 +196,11 @@ __global__ void __launch_bounds__(T) conv_wgrad_f32(const WgradArgs p)
     {
 #pragma unroll
       for (int j = 0; j < PA; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) As[(ar + 32 * j) * LS + 4 * aq + e] = ra[4 * j + e];
+      {
+        float2* const dst = (float2*)(As + (ar + 32 * j) * LS + 4 * aq);
+        dst[0] = make_float2(ra[4 * j + 0], ra[4 * j + 1]);
+        dst[1] = make_float2(ra[4 * j + 2], ra[4 * j + 3]);
+      }
     }
     else
     {
@@ -229,22 +234,30 @@ __global__ void __launch_bounds__(T) conv_wgrad_f32(const WgradArgs p)
         load_stage();
         advance();
       }
-      // A operand: lane (row m, kk = n); B operand: lane (kk = n, col k)
-      const float* ap = cur + (wm * 32 * TM + l31) * LS + lh;
-      const float* bp = cur + A_FL + (wk * 32 * TK + l31) * LS + lh;
+      // A operand: lane (row m, pixel); B operand: lane (pixel, col k).  One ds_read_b64 per operand feeds
+      // two MFMAs: lanes 0-31 hold pixels (4s, 4s+1) of the stage, lanes 32-63 pixels (4s+2, 4s+3), i.e. the
+      // contraction pairs are (4s, 4s+2) then (4s+1, 4s+3) -- the sum over pixels has no prescribed order here
+      // (it ends in float atomics across the pixel splits anyway)
+      const float* ap = cur + (wm * 32 * TM + l31) * LS + 2 * lh;
+      const float* bp = cur + A_FL + (wk * 32 * TK + l31) * LS + 2 * lh;
 #pragma unroll
-      for (int s = 0; s < NC / 2; ++s)
+      for (int s = 0; s < NC / 4; ++s)
       {
-        float a[TM], bb[TK];
+        float2 a[TM], bb[TK];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = ap[i * 32 * LS + 2 * s];
+        for (int i = 0; i < TM; ++i) a[i] = *(const float2*)(ap + i * 32 * LS + 4 * s);
 #pragma unroll
-        for (int j = 0; j < TK; ++j) bb[j] = bp[j * 32 * LS + 2 * s];
+        for (int j = 0; j < TK; ++j) bb[j] = *(const float2*)(bp + j * 32 * LS + 4 * s);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TK; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, bb[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TK; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, bb[j].y, acc[i][j], 0, 0, 0);
       }
       if (more)
         store_stage(lds + ((st + 1 - st_begin) & 1) * STAGE);
