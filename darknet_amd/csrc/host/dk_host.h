@@ -56,6 +56,9 @@ void FillUpsampleLayer(layer* l, int batch, int w, int h, int c, int stride);
 void FillDropoutLayer(layer* l, int batch, int inputs, float probability, int w, int h, int c);
 void FillYoloLayer(layer* l, int batch, int w, int h, int n, int total, int* mask, int classes,
     int max_boxes);
+void FillGaussianYoloLayer(layer* l, int batch, int w, int h, int n, int total, int* mask, int classes, int max_boxes);
+int DkGaussianYoloNumDetectionsBatch(layer const* l, int b, float thresh);
+int DkGetGaussianYoloDetectionsBatch(layer const* l, int b, int net_w, int net_h, float thresh, Detection* dets, int* ids);
 
 // the buffer readers of layer l's output use (a single-input [route] may alias its source)
 inline float* DkLayerOut(const layer* l) { return l->out_alias ? l->out_alias : l->output_gpu; }

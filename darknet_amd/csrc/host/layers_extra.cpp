@@ -273,3 +273,146 @@ void update_convolutional_layer_gpu(layer* l, int batch, float learning_rate, fl
 // The reference's init_cpu probes AVX/FMA for its CPU GEMM (utils.cpp / gemm.c); this library has no
 // CPU compute path, so there is nothing to initialise.
 void init_cpu(void) {}
+
+
+// ------------------------------------------------------------------ [Gaussian_yolo]
+// Inference and the pass-through backward of the reference's Gaussian YOLOv3 head
+// (src/gaussian_yolo_layer.cpp).  Its training loss (delta_gaussian_yolo_box :195-405, host code in the
+// reference too) is NOT built: a train-mode forward fails loudly instead of producing wrong deltas.
+void ForwardGaussianYoloLayerGpu(layer* l, NetworkState state)
+{
+  if (dk_gaussian_yolo_forward(state.input, l->output_gpu, l->batch, l->w, l->h, l->n, l->classes, l->scale_x_y,
+          get_cuda_stream()))
+    error("ForwardGaussianYoloLayerGpu failed");
+  if (state.train && !l->onlyforward)
+    error("[Gaussian_yolo]: the training loss (src/gaussian_yolo_layer.cpp:195-405) is out of scope; inference only");
+}
+
+// BackwardGaussianYoloLayerGpu, src/gaussian_yolo_layer.cpp:997-1000
+void BackwardGaussianYoloLayerGpu(layer* l, NetworkState state)
+{
+  if (state.delta)
+    dk_axpy((size_t)l->batch * l->inputs, 1.f, l->delta_gpu, state.delta, get_cuda_stream());
+}
+
+// FillGaussianYoloLayer, src/gaussian_yolo_layer.cpp:26-100
+void FillGaussianYoloLayer(layer* l, int batch, int w, int h, int n, int total, int* mask, int classes, int max_boxes)
+{
+  l->type = GAUSSIAN_YOLO;
+  l->n = n;
+  l->total = total;
+  l->batch = batch;
+  l->h = h; l->w = w;
+  l->c = n * (classes + 8 + 1);
+  l->out_w = l->w; l->out_h = l->h; l->out_c = l->c;
+  l->classes = classes;
+  l->cost = (float*)xcalloc(1, sizeof(float));
+  l->biases = (float*)xcalloc(total * 2, sizeof(float));
+  l->nbiases = total * 2;
+  if (mask)
+    l->mask = mask;
+  else
+  {
+    l->mask = (int*)xcalloc(n, sizeof(int));
+    for (int i = 0; i < n; ++i) l->mask[i] = i;
+  }
+  l->bias_updates = (float*)xcalloc(n * 2, sizeof(float));
+  l->outputs = h * w * n * (classes + 8 + 1);
+  l->inputs = l->outputs;
+  l->max_boxes = max_boxes;
+  l->truths = l->max_boxes * (4 + 1);
+  for (int i = 0; i < total * 2; ++i) l->biases[i] = .5;
+  l->forward = no_cpu_path;
+  l->backward = no_cpu_path;
+  l->forward_gpu = ForwardGaussianYoloLayerGpu;
+  l->backward_gpu = BackwardGaussianYoloLayerGpu;
+  const size_t total_out = (size_t)batch * l->outputs;
+  if (dk_gpu_enabled())
+  {
+    l->output_gpu = cuda_make_array(nullptr, total_out);
+    l->delta_gpu = cuda_make_array(nullptr, total_out);
+    CHECK_HIP(hipMemsetAsync(l->delta_gpu, 0, total_out * sizeof(float), get_cuda_stream()));
+    l->output = cuda_make_array_pinned(nullptr, total_out);   // pinned host mirror, as for [yolo]
+    l->output_pinned = 1;
+    memset(l->output, 0, total_out * sizeof(float));
+  }
+  else
+    l->output = (float*)xcalloc(total_out, sizeof(float));
+}
+
+// EntryGaussianIndex, src/gaussian_yolo_layer.cpp:477-484
+static int gaussian_entry_index(const layer* l, int batch, int location, int entry)
+{
+  const int n = location / (l->w * l->h);
+  const int loc = location % (l->w * l->h);
+  return batch * l->outputs + n * l->w * l->h * (8 + l->classes + 1) + entry * l->w * l->h + loc;
+}
+
+// GaussianYoloNumDetections :859-874, for batch item b
+int DkGaussianYoloNumDetectionsBatch(layer const* l, int b, float thresh)
+{
+  int count = 0;
+  for (int i = 0; i < l->w * l->h; ++i)
+    for (int n = 0; n < l->n; ++n)
+      if (l->output[gaussian_entry_index(l, b, n * l->w * l->h + i, 8)] > thresh)
+        ++count;
+  return count;
+}
+
+// GetGaussianYoloDetections :876-930 + GetGaussianYoloBox :151-177, for batch item b.  dets[k].uc (4 floats)
+// must be allocated by the caller (MakeNetworkBoxes does when the last layer is a Gaussian head).
+int DkGetGaussianYoloDetectionsBatch(layer const* l, int b, int net_w, int net_h, float thresh, Detection* dets, int* ids)
+{
+  float const* pred = l->output;
+  const int stride = l->w * l->h;
+  int count = 0;
+  for (int n = 0; n < l->n; ++n)
+    for (int i = 0; i < l->w * l->h; ++i)
+    {
+      const int loc = n * l->w * l->h + i;
+      const float objectness = pred[gaussian_entry_index(l, b, loc, 8)];
+      if (objectness <= thresh)
+        continue;
+      const int box = gaussian_entry_index(l, b, loc, 0);
+      const int col = i % l->w, row = i / l->w;
+      const int a = l->mask[n];
+      Box bx;
+      bx.w = expf(pred[box + 4 * stride]) * l->biases[2 * a] / net_w;
+      bx.h = expf(pred[box + 6 * stride]) * l->biases[2 * a + 1] / net_h;
+      bx.x = (col + pred[box + 0 * stride]) / l->w;
+      bx.y = (row + pred[box + 2 * stride]) / l->h;
+      if (l->yolo_point == YOLO_LEFT_TOP)
+      {
+        bx.x = (col + pred[box + 0 * stride]) / l->w + bx.w / 2;
+        bx.y = (row + pred[box + 2 * stride]) / l->h + bx.h / 2;
+      }
+      else if (l->yolo_point == YOLO_RIGHT_BOTTOM)
+      {
+        bx.x = (col + pred[box + 0 * stride]) / l->w - bx.w / 2;
+        bx.y = (row + pred[box + 2 * stride]) / l->h - bx.h / 2;
+      }
+      dets[count].bbox = bx;
+      dets[count].objectness = objectness;
+      dets[count].classes = l->classes;
+      float uc[4];
+      for (int k = 0; k < 4; ++k) uc[k] = pred[gaussian_entry_index(l, b, loc, 2 * k + 1)];
+      if (dets[count].uc)
+        for (int k = 0; k < 4; ++k) dets[count].uc[k] = uc[k];
+      dets[count].points = l->yolo_point;
+      for (int j = 0; j < l->classes; ++j)
+      {
+        const float uc_avg = (uc[0] + uc[1] + uc[2] + uc[3]) / 4.0;
+        const float prob = objectness * pred[gaussian_entry_index(l, b, loc, 9 + j)] * (1.0 - uc_avg);
+        dets[count].prob[j] = (prob > thresh) ? prob : 0;
+      }
+      if (ids)
+      {
+        ids[4 * count + 0] = -1;
+        ids[4 * count + 1] = n;
+        ids[4 * count + 2] = row;
+        ids[4 * count + 3] = col;
+      }
+      ++count;
+    }
+  return count;
+}

@@ -619,7 +619,7 @@ void NetworkPredictDevice(Network* net, float* input_gpu)
     for (int i = 0; i < net->n; ++i)
     {
       layer* l = &net->layers[i];
-      if (l->type == YOLO)
+      if (l->type == YOLO || l->type == GAUSSIAN_YOLO)
         CHECK_HIP(hipMemcpyAsync(l->output, l->output_gpu,
             (size_t)l->batch * l->outputs * sizeof(float), hipMemcpyDeviceToHost, cs));
     }
@@ -646,7 +646,7 @@ float* GetNetworkOutputGpu(Network* net)
       break;
   layer* l = &net->layers[i];
   NetworkSync(net);
-  if (l->type != YOLO || !net_pull_heads(net))
+  if ((l->type != YOLO && l->type != GAUSSIAN_YOLO) || !net_pull_heads(net))
     cuda_pull_array(l->output_gpu, l->output, (size_t)l->outputs * l->batch);
   return l->output;
 }
@@ -961,7 +961,16 @@ static int candidates_to_dets(Network* net, int b, float thresh, Detection* dets
   return out;
 }
 
-static bool heads_on_device(Network* net) { return !net_pull_heads(net) && net->gpu_index >= 0; }
+// (the device-side candidate compaction knows the [yolo] record layout only: nets with [Gaussian_yolo]
+// heads always pull their heads)
+static bool has_gaussian_heads(const Network* net)
+{
+  for (int i = 0; i < net->n; ++i)
+    if (net->layers[i].type == GAUSSIAN_YOLO)
+      return true;
+  return false;
+}
+static bool heads_on_device(Network* net) { return !net_pull_heads(net) && net->gpu_index >= 0 && !has_gaussian_heads(net); }
 
 static int num_detections(Network* net, int b, float thresh)
 {
@@ -973,8 +982,12 @@ static int num_detections(Network* net, int b, float thresh)
   }
   int s = 0;
   for (int i = 0; i < net->n; ++i)
+  {
     if (net->layers[i].type == YOLO)
       s += DkYoloNumDetectionsBatch(&net->layers[i], b, thresh);
+    else if (net->layers[i].type == GAUSSIAN_YOLO)
+      s += DkGaussianYoloNumDetectionsBatch(&net->layers[i], b, thresh);
+  }
   return s;
 }
 
@@ -985,7 +998,12 @@ static Detection* make_boxes(Network* net, int b, float thresh, int* num)
   if (num)
     *num = num_boxes;
   Detection* dets = (Detection*)xcalloc(num_boxes, sizeof(Detection));
-  for (int i = 0; i < num_boxes; ++i) dets[i].prob = (float*)xcalloc(l->classes, sizeof(float));
+  for (int i = 0; i < num_boxes; ++i)
+  {
+    dets[i].prob = (float*)xcalloc(l->classes, sizeof(float));
+    if (l->type == GAUSSIAN_YOLO)   // tx, ty, tw, th uncertainty (network.cpp:449-452)
+      dets[i].uc = (float*)xcalloc(4, sizeof(float));
+  }
   return dets;
 }
 
@@ -1010,6 +1028,8 @@ Detection* GetNetworkBoxesBatch(Network* net, int b, float thresh, int* num)
     layer* l = &net->layers[i];
     if (l->type == YOLO)
       d += DkGetYoloDetectionsBatch(l, b, net->w, net->h, thresh, d, nullptr);
+    else if (l->type == GAUSSIAN_YOLO)
+      d += DkGetGaussianYoloDetectionsBatch(l, b, net->w, net->h, thresh, d, nullptr);
   }
   return dets;
 }
@@ -1125,15 +1145,17 @@ int DkGetBoxesBatch(Network* net, int b, float thresh, float* out, int* ids, int
   for (int i = 0; i < net->n; ++i)
   {
     layer* l = &net->layers[i];
-    if (l->type != YOLO)
+    if (l->type != YOLO && l->type != GAUSSIAN_YOLO)
       continue;
-    const int num = DkYoloNumDetectionsBatch(l, b, thresh);
+    const bool gauss = l->type == GAUSSIAN_YOLO;
+    const int num = gauss ? DkGaussianYoloNumDetectionsBatch(l, b, thresh) : DkYoloNumDetectionsBatch(l, b, thresh);
     if (num == 0)
       continue;
     Detection* dets = (Detection*)xcalloc(num, sizeof(Detection));
     for (int k = 0; k < num; ++k) dets[k].prob = (float*)xcalloc(l->classes, sizeof(float));
     int* lid = (int*)xcalloc((size_t)num * 4, sizeof(int));
-    const int got = DkGetYoloDetectionsBatch(l, b, net->w, net->h, thresh, dets, lid);
+    const int got = gauss ? DkGetGaussianYoloDetectionsBatch(l, b, net->w, net->h, thresh, dets, lid)
+                          : DkGetYoloDetectionsBatch(l, b, net->w, net->h, thresh, dets, lid);
     const int rec = 5 + l->classes;
     for (int k = 0; k < got; ++k)
     {

@@ -229,6 +229,64 @@ static void ParseYolo(layer* l, Section& o, SizeParams params)
   }
 }
 
+// ParseGaussianYolo, src/parser.cpp:443-552 (inference fields; the loss options are accepted and kept)
+static void ParseGaussianYolo(layer* l, Section& o, SizeParams params)
+{
+  int classes = FindOptionInt(o, "classes", 20);
+  int max_boxes = FindOptionIntQuiet(o, "max", 90);
+  int total = FindOptionInt(o, "num", 1);
+  int num = total;
+  int* mask = parse_int_list(FindOptionStr(o, "mask", 0), &num);
+  FillGaussianYoloLayer(l, params.batch, params.w, params.h, num, total, mask, classes, max_boxes);
+  if (l->outputs != params.inputs)
+  {
+    printf("Error: l->outputs == params.inputs \n");
+    printf("filters= in the [convolutional]-layer doesn't correspond to classes= or mask= in "
+           "[Gaussian_yolo]-layer \n");
+    exit(EXIT_FAILURE);
+  }
+  (void)FindOption(o, "counters_per_class");
+  l->label_smooth_eps = FindOptionFloatQuiet(o, "label_smooth_eps", 0.0f);
+  l->scale_x_y = FindOptionFloatQuiet(o, "scale_x_y", 1);
+  l->max_delta = FindOptionFloatQuiet(o, "max_delta", FLT_MAX);
+  (void)FindOptionFloatQuiet(o, "uc_normalizer", 1.0f);
+  l->iou_normalizer = FindOptionFloatQuiet(o, "iou_normalizer", 0.75);
+  l->cls_normalizer = FindOptionFloatQuiet(o, "cls_normalizer", 1);
+  const char* iou_loss = FindOptionStrQuiet(o, "iou_loss", "mse");
+  if (strcmp(iou_loss, "mse") == 0) l->iou_loss = MSE;
+  else if (strcmp(iou_loss, "giou") == 0) l->iou_loss = GIOU;
+  else if (strcmp(iou_loss, "diou") == 0) l->iou_loss = DIOU;
+  else if (strcmp(iou_loss, "ciou") == 0) l->iou_loss = CIOU;
+  else l->iou_loss = IOU;
+  const char* itk = FindOptionStrQuiet(o, "iou_thresh_kind", "iou");
+  if (strcmp(itk, "giou") == 0) l->iou_thresh_kind = GIOU;
+  else if (strcmp(itk, "diou") == 0) l->iou_thresh_kind = DIOU;
+  else if (strcmp(itk, "ciou") == 0) l->iou_thresh_kind = CIOU;
+  else l->iou_thresh_kind = IOU;
+  l->beta_nms = FindOptionFloatQuiet(o, "beta_nms", 0.6);
+  const char* nms_kind = FindOptionStrQuiet(o, "nms_kind", "greedynms");
+  l->nms_kind = (strcmp(nms_kind, "diounms") == 0) ? DIOU_NMS : GREEDY_NMS;
+  const char* yp = FindOptionStrQuiet(o, "yolo_point", "center");
+  l->yolo_point = strcmp(yp, "left_top") == 0 ? YOLO_LEFT_TOP : (strcmp(yp, "right_bottom") == 0 ? YOLO_RIGHT_BOTTOM : YOLO_CENTER);
+  l->jitter = FindOptionFloatQuiet(o, "jitter", .2);
+  l->ignore_thresh = FindOptionFloatQuiet(o, "ignore_thresh", .5);
+  l->truth_thresh = FindOptionFloatQuiet(o, "truth_thresh", 1);
+  l->iou_thresh = FindOptionFloatQuiet(o, "iou_thresh", 1);
+  l->random = FindOptionFloatQuiet(o, "random", 0);
+  (void)FindOption(o, "map");
+  const char* a = FindOptionStr(o, "anchors", 0);
+  if (a)
+  {
+    int n = count_commas(a);
+    for (int i = 0; i < n && i < total * 2; ++i)
+    {
+      l->biases[i] = (float)atof(a);
+      const char* nx = strchr(a, ',');
+      a = nx ? nx + 1 : a + strlen(a);
+    }
+  }
+}
+
 static void ParseMaxpool(layer* l, Section& o, SizeParams params)
 {
   int stride = FindOptionInt(o, "stride", 1);
@@ -436,6 +494,8 @@ static bool parse_cfg_batch(Network* net, char const* filename, bool train, int 
       ParseConv(l, s, params);
     else if (s.type == "[yolo]")
       ParseYolo(l, s, params);
+    else if (s.type == "[Gaussian_yolo]")
+      ParseGaussianYolo(l, s, params);
     else if (s.type == "[maxpool]" || s.type == "[max]")
       ParseMaxpool(l, s, params);
     else if (s.type == "[route]")

@@ -181,10 +181,11 @@ void ResizeNetwork(Network* net, int w, int h)
         resize_layer_buffers(l, false);
         break;
       case YOLO:
+      case GAUSSIAN_YOLO:
       {
         l->w = w; l->h = h;
         l->out_w = w; l->out_h = h;
-        l->outputs = h * w * l->n * (l->classes + 4 + 1);
+        l->outputs = h * w * l->n * (l->classes + (l->type == GAUSSIAN_YOLO ? 8 : 4) + 1);
         l->inputs = l->outputs;
         const size_t total = (size_t)l->batch * l->outputs;
         if (gpu)
@@ -223,7 +224,7 @@ void ResizeNetwork(Network* net, int w, int h)
     h = l->out_h;
   }
   net->outputs = GetNetworkOutputSize(net);
-  if (net->layers[net->n - 1].type == YOLO)
+  if (net->layers[net->n - 1].type == YOLO || net->layers[net->n - 1].type == GAUSSIAN_YOLO)
     net->output = net->layers[net->n - 1].output;
   if (gpu)
   {

@@ -339,7 +339,13 @@ extern "C" int dk_conv_backward_weights(const DkConvDesc* d, const float* x, con
     a.N = nb * OH * OW;
     a.size = d->size; a.stride_x = d->stride_x; a.stride_y = d->stride_y;
     a.pad = pad; a.dil = d->dilation;
-    const int ci = (M > 64 ? 0 : 1) + (K > 64 ? 0 : 2);  // 128/64 rows x 128/64 taps
+    int ci = (M > 64 ? 0 : 1) + (K > 64 ? 0 : 2);  // 128/64 rows x 128/64 taps
+    {
+      // DK_WGRAD_TILE=1/2/3: force 64x128 / 128x64 / 64x64 tiles (tuning experiments)
+      static const int force = getenv("DK_WGRAD_TILE") ? atoi(getenv("DK_WGRAD_TILE")) : 0;
+      if (force > 0 && force < 4)
+        ci |= force;
+    }
     const WgradCfg& c = g_wcfg[ci];
     const int BM = 64 * c.tm, BKO = 64 * c.tk;
     a.tiles_m = (M + BM - 1) / BM;

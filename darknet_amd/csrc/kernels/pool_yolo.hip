@@ -148,6 +148,23 @@ __global__ void yolo_decode_kernel(const float* __restrict__ in, float* __restri
     out[i] = v;
   }
 }
+// ForwardGaussianYoloLayerGpu decode (src/gaussian_yolo_layer.cpp:934-966) in one launch: entry e of anchor
+// a lives at b*outputs + a*(9+cls)*wh + e*wh + loc; logistic on entries 0-3, 5, 7 and 8.., scale_x_y on the two
+// mu planes (entries 0 and 2), entries 4 and 6 (mu of w, h) pass through.
+__global__ void gaussian_yolo_decode_kernel(const float* __restrict__ in, float* __restrict__ out, size_t total, int wh,
+    int entries, float scale_x_y, float beta)
+{
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+  {
+    const int e = (int)((i / wh) % entries);
+    float v = in[i];
+    if (e != 4 && e != 6)
+      v = dk_logistic(v);
+    if (e == 0 || e == 2)
+      v = v * scale_x_y + beta;  // scal_add_cpu, src/blas.c:252-256
+    out[i] = v;
+  }
+}
 // Candidate compaction of GetYoloDetections (src/yolo_layer.cpp:794-834): every predictor
 // whose objectness exceeds thresh appends one record {layer tag, image, loc = n*wh + i,
 // x, y, w, h, objectness, class scores (raw decoded values)} to a shared list.  The host
@@ -365,6 +382,25 @@ extern "C" int dk_yolo_forward(const float* in, float* out, int batch, int lw, i
   const float beta = (float)(-0.5 * (scale_x_y - 1));  // yolo_layer.cpp:400
   hipLaunchKernelGGL(yolo_decode_kernel, dim3(grid_for(total)), dim3(256), 0, S(stream), in, out,
       total, lw * lh, entries, scale_x_y, beta);
+  CHECK_HIP(hipPeekAtLastError());
+  return 0;
+}
+
+extern "C" int dk_gaussian_yolo_forward(const float* in, float* out, int batch, int lw, int lh, int n_anchors,
+    int classes, float scale_x_y, void* stream)
+{
+  if (!in || !out)
+  {
+    fprintf(stderr, "dk_gaussian_yolo_forward: invalid arguments\n");
+    return 1;
+  }
+  const int entries = classes + 8 + 1;
+  const size_t total = (size_t)batch * n_anchors * entries * lw * lh;
+  if (total == 0)
+    return 0;
+  const float beta = (float)(-0.5 * (scale_x_y - 1));
+  hipLaunchKernelGGL(gaussian_yolo_decode_kernel, dim3(grid_for(total)), dim3(256), 0, S(stream), in, out, total,
+      lw * lh, entries, scale_x_y, beta);
   CHECK_HIP(hipPeekAtLastError());
   return 0;
 }

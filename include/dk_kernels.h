@@ -151,6 +151,9 @@ DK_API int dk_image_resize_u8_to_chw(const unsigned char* src_hwc, int src_w, in
  * logistic on objectness and classes; w,h raw. */
 DK_API int dk_yolo_forward(const float* in, float* out, int batch, int lw, int lh,
     int n_anchors, int classes, float scale_x_y, void* stream);
+/* [Gaussian_yolo] decode (src/gaussian_yolo_layer.cpp:934-966): (8 + 1 + classes) entries per anchor */
+DK_API int dk_gaussian_yolo_forward(const float* in, float* out, int batch, int lw, int lh, int n_anchors,
+    int classes, float scale_x_y, void* stream);
 
 /* activate_array_ongpu, src/activation_kernels.cu:505-560 (in place). */
 DK_API int dk_activate_array(float* x, size_t n, int activation, void* stream);

@@ -54,6 +54,14 @@ typedef enum
 
 typedef enum { IOU, GIOU, MSE, DIOU, CIOU } IOU_LOSS;      /* src/box.h:6-13 */
 typedef enum { GREEDY_NMS, DIOU_NMS } NMS_KIND;            /* src/box.h:15-19 */
+
+/* yolo_core.h:94-100 */
+typedef enum
+{
+  YOLO_CENTER = 1 << 0,
+  YOLO_LEFT_TOP = 1 << 1,
+  YOLO_RIGHT_BOTTOM = 1 << 2
+} YOLO_POINT;
 typedef enum
 { /* src/yolo_core.h:440-450 */
   CONSTANT, STEP, EXP, POLY, STEPS, SIG, RANDOM, SGDR
@@ -177,6 +185,7 @@ struct layer
   float* classes_multipliers;
   IOU_LOSS iou_loss, iou_thresh_kind;
   NMS_KIND nms_kind;
+  YOLO_POINT yolo_point; /* [Gaussian_yolo]: which point of the box the head predicts */
   int* map;
 
   /* per-layer common keys, src/parser.cpp:1361-1369 */
@@ -467,6 +476,8 @@ LIB_API void ForwardRouteLayerGpu(layer* l, NetworkState state);
 LIB_API void ForwardShortcutLayerGpu(layer* l, NetworkState state);
 LIB_API void ForwardUpsampleLayerGpu(layer* l, NetworkState state);
 LIB_API void ForwardYoloLayerGpu(layer* l, NetworkState state);
+LIB_API void ForwardGaussianYoloLayerGpu(layer* l, NetworkState state);   /* inference; src/gaussian_yolo_layer.cpp:934 */
+LIB_API void BackwardGaussianYoloLayerGpu(layer* l, NetworkState state);
 LIB_API int YoloNumDetections(layer const* l, float thresh);
 LIB_API int GetYoloDetections(layer const* l, int net_w, int net_h, float thresh, Detection* dets);
 

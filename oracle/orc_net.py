@@ -40,6 +40,7 @@ ACT_NAMES = {"logistic": LOGISTIC, "relu": RELU, "linear": LINEAR,
              "swish": 16}
 CONVOLUTIONAL, MAXPOOL, ROUTE, SHORTCUT, YOLO, UPSAMPLE = 0, 2, 7, 11, 17, 21
 DROPOUT, AVGPOOL, SCALE_CHANNELS, BATCHNORM = 5, 9, 12, 14
+GAUSSIAN_YOLO = 18   # LAYER_TYPE, yolo_core.h (YOLO = 17)
 
 _lib = None
 
@@ -235,6 +236,25 @@ def parse_cfg(path, batch=1, train=False):
             l.out_c = l.n * (l.classes + 4 + 1)
             assert l.out_c == c, "filters= before [yolo] does not match classes/mask"
             l.bflops = 0
+        elif name == "[Gaussian_yolo]":
+            # ParseGaussianYolo / FillGaussianYoloLayer, src/parser.cpp:443-552, src/gaussian_yolo_layer.cpp:26-100
+            l.type = GAUSSIAN_YOLO
+            l.classes = _int(o, "classes", 20)
+            l.total = _int(o, "num", 1)
+            l.mask = [int(x) for x in o["mask"].split(",")] if "mask" in o else list(range(l.total))
+            l.n = len(l.mask)
+            l.scale_x_y = _float(o, "scale_x_y", 1)
+            l.biases = np.full(l.total * 2, .5, np.float32)
+            if "anchors" in o:
+                a = [float(x) for x in o["anchors"].split(",")]
+                for i in range(min(len(a), l.total * 2)):
+                    l.biases[i] = a[i]
+            l.nms_kind = {"greedynms": 0, "diounms": 1}.get(o.get("nms_kind", "greedynms"), 0)
+            l.beta_nms = _float(o, "beta_nms", 0.6)
+            l.out_w, l.out_h = w, h
+            l.out_c = l.n * (l.classes + 8 + 1)
+            assert l.out_c == c, "filters= before [Gaussian_yolo] does not match classes/mask"
+            l.bflops = 0
         elif name == "[batchnorm]":
             # FillBatchnormLayer, src/batchnorm_layer.cpp:9-88
             l.type = BATCHNORM
@@ -388,6 +408,8 @@ def forward(net, x, keep=None, upto=None, half=False):
         elif l.type == YOLO:
             L.orc_yolo_forward(fptr(inp), fptr(out), B, l.w, l.h, l.n, l.classes,
                                F(l.scale_x_y))
+        elif l.type == GAUSSIAN_YOLO:
+            L.orc_gaussian_yolo_forward(fptr(inp), fptr(out), B, l.w, l.h, l.n, l.classes, F(l.scale_x_y))
         else:
             out = _forward_extra(L, net, l, inp, out, train=False)
         l.output = out
@@ -436,6 +458,13 @@ def get_boxes(net, thresh, b=0):
     L = lib()
     dets, ids = [], []
     for l in net.layers:
+        if l.type == GAUSSIAN_YOLO:
+            # GetGaussianYoloDetections: the record also carries the four uncertainties (dropped here; see
+            # get_gaussian_boxes for them)
+            d, i3 = _gaussian_dets(L, net, l, thresh, b)
+            dets.append(d[:, :5 + l.classes])
+            ids.append(np.concatenate([np.full((len(d), 1), l.index, np.int32), i3], 1))
+            continue
         if l.type != YOLO:
             continue
         num = L.orc_yolo_num_detections(fptr(l.output), b, l.w, l.h, l.n,
@@ -452,6 +481,24 @@ def get_boxes(net, thresh, b=0):
     if not dets:
         return np.zeros((0, 5), np.float32), np.zeros((0, 4), np.int32)
     return np.concatenate(dets), np.concatenate(ids)
+
+
+def _gaussian_dets(L, net, l, thresh, b):
+    num = L.orc_gaussian_yolo_num_detections(fptr(l.output), b, l.w, l.h, l.n, l.classes, F(thresh))
+    d = np.zeros((num, 5 + l.classes + 4), np.float32)
+    i3 = np.zeros((num, 3), np.int32)
+    mask = np.array(l.mask, np.int32)
+    got = L.orc_gaussian_yolo_detections(fptr(l.output), b, l.w, l.h, l.n, l.classes, fptr(l.biases), iptr(mask),
+                                         net.w, net.h, F(thresh), fptr(d), iptr(i3))
+    assert got == num
+    return d, i3
+
+
+def get_gaussian_boxes(net, thresh, b=0):
+    """Detections of the [Gaussian_yolo] heads with their uncertainties: [num, 5 + classes + 4]."""
+    L = lib()
+    out = [_gaussian_dets(L, net, l, thresh, b)[0] for l in net.layers if l.type == GAUSSIAN_YOLO]
+    return np.concatenate(out) if out else np.zeros((0, 9), np.float32)
 
 
 # ------------------------------------------------------------------ training

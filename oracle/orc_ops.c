@@ -1083,3 +1083,98 @@ void orc_batchnorm_update(float* biases, float* bias_updates, float* scales, flo
   for (int i = 0; i < c; ++i) scales[i] += (learning_rate / batch) * scale_updates[i];
   for (int i = 0; i < c; ++i) scale_updates[i] *= momentum;
 }
+
+
+/* ---- [Gaussian_yolo] head, inference ------------------------------------------
+ * EntryGaussianIndex src/gaussian_yolo_layer.cpp:477-484: 8 box entries (mu/sigma of x, y, w, h) +
+ * objectness + classes per anchor. */
+static int gaussian_entry_index(int lw, int lh, int classes, int outputs, int batch, int location, int entry)
+{
+  int n = location / (lw * lh);
+  int loc = location % (lw * lh);
+  return batch * outputs + n * lw * lh * (8 + classes + 1) + entry * lw * lh + loc;
+}
+
+/* ForwardGaussianYoloLayer, inference part (src/gaussian_yolo_layer.cpp:486-518; the GPU twin :934-966
+ * applies the same activations): logistic on entries 0-3 (x, y: mu and sigma), 5, 7 (sigma of w, h) and
+ * 8.. (objectness, classes); scale_x_y on the two mu planes; entries 4 and 6 (mu of w, h) stay raw. */
+void orc_gaussian_yolo_forward(const float* input, float* output, int batch, int lw, int lh, int n_anchors,
+    int classes, float scale_x_y)
+{
+  const int outputs = lh * lw * n_anchors * (classes + 8 + 1);
+  const int wh = lw * lh;
+  memcpy(output, input, (size_t)outputs * batch * sizeof(float));
+  const float beta = -0.5 * (scale_x_y - 1);
+  for (int b = 0; b < batch; ++b)
+    for (int n = 0; n < n_anchors; ++n)
+    {
+      for (int e = 0; e <= 2; e += 2)
+      {
+        int index = gaussian_entry_index(lw, lh, classes, outputs, b, n * wh, e);
+        orc_activate_array_plain(output + index, 2 * wh, ORC_LOGISTIC);
+        for (int i = 0; i < wh; ++i) output[index + i] = output[index + i] * scale_x_y + beta;
+      }
+      orc_activate_array_plain(output + gaussian_entry_index(lw, lh, classes, outputs, b, n * wh, 5), wh, ORC_LOGISTIC);
+      orc_activate_array_plain(output + gaussian_entry_index(lw, lh, classes, outputs, b, n * wh, 7), wh, ORC_LOGISTIC);
+      orc_activate_array_plain(output + gaussian_entry_index(lw, lh, classes, outputs, b, n * wh, 8), (1 + classes) * wh,
+          ORC_LOGISTIC);
+    }
+}
+
+/* GaussianYoloNumDetections :859-874, generalised to batch item b */
+int orc_gaussian_yolo_num_detections(const float* output, int b, int lw, int lh, int n_anchors, int classes, float thresh)
+{
+  const int outputs = lh * lw * n_anchors * (classes + 8 + 1);
+  int count = 0;
+  for (int i = 0; i < lw * lh; ++i)
+    for (int n = 0; n < n_anchors; ++n)
+      if (output[gaussian_entry_index(lw, lh, classes, outputs, b, n * lw * lh + i, 8)] > thresh)
+        ++count;
+  return count;
+}
+
+/* GetGaussianYoloDetections :876-930 + GetGaussianYoloBox :151-177 (yolo_point = center).
+ * dets: per detection [x, y, w, h, objectness, prob[classes], uc[4]]; ids: [anchor, row, col]. */
+int orc_gaussian_yolo_detections(const float* output, int b, int lw, int lh, int n_anchors, int classes,
+    const float* biases, const int* mask, int net_w, int net_h, float thresh, float* dets, int* ids)
+{
+  const int outputs = lh * lw * n_anchors * (classes + 8 + 1);
+  const int stride = lw * lh;
+  const int rec = 5 + classes + 4;
+  int count = 0;
+  for (int n = 0; n < n_anchors; ++n)
+    for (int i = 0; i < lw * lh; ++i)
+    {
+      int loc = n * lw * lh + i;
+      float objectness = output[gaussian_entry_index(lw, lh, classes, outputs, b, loc, 8)];
+      if (objectness <= thresh)
+        continue;
+      int box = gaussian_entry_index(lw, lh, classes, outputs, b, loc, 0);
+      int col = i % lw, row = i / lw;
+      int a = mask[n];
+      float* d = dets + (size_t)count * rec;
+      d[2] = expf(output[box + 4 * stride]) * biases[2 * a] / net_w;
+      d[3] = expf(output[box + 6 * stride]) * biases[2 * a + 1] / net_h;
+      d[0] = (col + output[box + 0 * stride]) / lw;
+      d[1] = (row + output[box + 2 * stride]) / lh;
+      d[4] = objectness;
+      float uc[4];
+      for (int k = 0; k < 4; ++k) uc[k] = output[gaussian_entry_index(lw, lh, classes, outputs, b, loc, 2 * k + 1)];
+      for (int j = 0; j < classes; ++j)
+      {
+        float cls = output[gaussian_entry_index(lw, lh, classes, outputs, b, loc, 9 + j)];
+        float uc_avg = (uc[0] + uc[1] + uc[2] + uc[3]) / 4.0;
+        float prob = objectness * cls * (1.0 - uc_avg);
+        d[5 + j] = (prob > thresh) ? prob : 0;
+      }
+      for (int k = 0; k < 4; ++k) d[5 + classes + k] = uc[k];
+      if (ids)
+      {
+        ids[3 * count + 0] = n;
+        ids[3 * count + 1] = row;
+        ids[3 * count + 2] = col;
+      }
+      ++count;
+    }
+  return count;
+}

@@ -166,3 +166,48 @@ def test_standalone_batchnorm_train_step_vs_oracle(gpu, tmp_path):
     util.assert_close(s1 - s0, np.float32(lr / onet.batch) * su, "[batchnorm] scale update", rel=2e-3, atol_rms=2e-3)
     util.assert_close(b1 - b0, np.float32(lr / onet.batch) * bu, "[batchnorm] bias update", rel=2e-3, atol_rms=2e-3)
     net.close()
+
+
+def test_gaussian_yolo_heads_vs_reference_golden(gpu, tmp_path):
+    """[Gaussian_yolo] (src/gaussian_yolo_layer.cpp), inference: cfg/gaussian-test.cfg at batch 2 -- both decoded
+    heads vs the oracle and, for item 0, vs the REAL reference (tests/golden/gaussian-test.npz); the detection
+    list (location indices exact, boxes / objectness / uncertainty-weighted class probabilities within the fp32
+    tolerance) for both images; pulled-heads and DkSetPullHeads(0) give the same list (nets with Gaussian heads
+    always pull)."""
+    g = np.load(os.path.join(GOLD, "gaussian-test.npz"))
+    cfg = os.path.join(os.path.dirname(GOLD), "..", "cfg", "gaussian-test.cfg")
+    cfg = os.path.normpath(cfg)
+    onet = O.parse_cfg(cfg)
+    w = str(tmp_path / "w.weights")
+    synth.write_weights_layers(w, synth.weight_layers_of(onet), seed=2024)
+    assert os.path.getsize(w) == int(g["weights_bytes"])
+    B = 2
+    x = np.concatenate([synth.make_input(1, onet.c, onet.h, onet.w, seed=12345),
+                        synth.make_input(1, onet.c, onet.h, onet.w, seed=4242)])
+    onet = O.load_network(cfg, w, batch=B)
+    O.forward(onet, x)
+    L = gpu.lib()
+    net = netutil.DkNet(gpu, cfg, w, batch=B)
+    assert net.n == int(g["n_layers"])
+    thresh = float(g["thresh"])
+    for pull in (1, 0):
+        L.DkSetPullHeads(pull)
+        net.predict(x)
+        for i, l in enumerate(onet.layers):
+            got = net.output(i)
+            util.assert_close(got, l.output, "gaussian-test layer %d (type %d)" % (i, l.type))
+            if l.type == O.GAUSSIAN_YOLO:
+                assert net.info(i)["type"] == O.GAUSSIAN_YOLO
+                util.assert_close(got[0], g["head_%d" % i], "gaussian head %d vs the reference" % i)
+        d0, ids0 = net.boxes(0, thresh)
+        assert np.array_equal(ids0, g["det_ids"]), "detection indices differ from the reference"
+        util.assert_close(d0, g["dets"], "gaussian detections vs the reference")
+        od, oids = O.get_boxes(onet, thresh, 1)
+        d1, ids1 = net.boxes(1, thresh)
+        clear = np.abs(od[:, 4] - thresh) > 1e-4     # item 1 has no guard band of its own
+        if np.array_equal(ids1, oids):
+            util.assert_close(d1, od, "gaussian detections image 1 vs the oracle")
+        else:
+            assert abs(len(ids1) - len(oids)) <= (~clear).sum()
+    L.DkSetPullHeads(1)
+    net.close()

@@ -237,3 +237,24 @@ def test_rare_activation_gradients_golden(ops):
     d = np.ones_like(y)
     L.orc_gradient_array_swish(O.fptr(y), y.size, O.fptr(np.ascontiguousarray(gg["swish_sigmoid"])), O.fptr(d))
     assert np.array_equal(d, gg["grad_swish"])
+
+
+def test_gaussian_yolo_oracle_vs_reference_golden(tmp_path):
+    """[Gaussian_yolo] heads: the oracle's decoded heads and detection list on
+    cfg/gaussian-test.cfg are bit-identical to the REAL reference's (tests/golden/gaussian-test.npz,
+    tools/make_golden.py gaussian)."""
+    g = np.load(os.path.join(GOLD, "gaussian-test.npz"))
+    cfg = os.path.join(ROOT, "cfg", "gaussian-test.cfg")
+    net = O.parse_cfg(cfg)
+    w = str(tmp_path / "w.weights")
+    synth.write_weights_layers(w, synth.weight_layers_of(net), seed=2024)
+    assert os.path.getsize(w) == int(g["weights_bytes"]) == O.weights_file_size(net)
+    net = O.load_network(cfg, w, batch=1)
+    O.forward(net, synth.make_input(1, net.c, net.h, net.w, seed=12345))
+    heads = [i for i, l in enumerate(net.layers) if l.type == O.GAUSSIAN_YOLO]
+    assert len(heads) == 2 and net.n == int(g["n_layers"])
+    for i in heads:
+        assert np.array_equal(net.layers[i].output.ravel(), g["head_%d" % i])
+    d, ids = O.get_boxes(net, float(g["thresh"]))
+    assert np.array_equal(d, g["dets"]) and np.array_equal(ids, g["det_ids"])
+    assert np.array_equal(O.get_gaussian_boxes(net, float(g["thresh"]))[:, -4:], g["dets_uc"])

@@ -244,6 +244,46 @@ def gen_net(name, full_heads):
     print(f"net_{name}.npz: layers {rn.n}, dets {len(dets)} at thresh {thresh:.6f}")
 
 
+def gen_gaussian():
+    """[Gaussian_yolo] heads, inference, through the REAL reference: every layer's output of
+    cfg/gaussian-test.cfg and the detection list (box, objectness, probabilities weighted by 1 - mean
+    uncertainty) at a guard-banded threshold; the oracle is asserted bit-identical -> gaussian-test.npz."""
+    name = "gaussian-test"
+    cfg = os.path.join(ROOT, "cfg", name + ".cfg")
+    net = O.parse_cfg(cfg)
+    wpath = "/tmp/_dk_gaussian.weights"
+    synth.write_weights_layers(wpath, synth.weight_layers_of(net), seed=2024)
+    x = synth.make_input(1, net.c, net.h, net.w, seed=12345)
+    rn = reflib.RefNet(cfg, wpath, train=False)
+    rn.predict(x)
+    onet = O.load_network(cfg, wpath, batch=1)
+    O.forward(onet, x)
+    out = {"n_layers": np.int32(rn.n), "weights_bytes": np.int64(os.path.getsize(wpath))}
+    allv = []
+    for i, l in enumerate(onet.layers):
+        inf = rn.info(i)
+        assert (inf["type"], inf["outputs"]) == (l.type, l.outputs), (i, inf)
+        r = rn.output(i)
+        assert np.array_equal(r, l.output.ravel()), f"gaussian: oracle != reference at layer {i}"
+        if l.type == O.GAUSSIAN_YOLO:
+            out[f"head_{i}"] = r
+            v = r.reshape(l.n, 9 + l.classes, l.w * l.h)
+            uc = (v[:, 1] + v[:, 3] + v[:, 5] + v[:, 7]) / 4
+            allv.append(v[:, 8].ravel())
+            allv.append((v[:, 8:9] * v[:, 9:] * (1 - uc[:, None])).ravel())
+    thresh = pick_threshold(np.concatenate(allv), lo=0.2, hi=0.6, guard=1e-4)
+    dets = rn.boxes(thresh)
+    od, oid = O.get_boxes(onet, thresh)
+    assert len(dets) > 50 and np.array_equal(od, dets), "gaussian: oracle and reference detections differ"
+    out["thresh"] = np.float32(thresh)
+    out["dets"] = dets
+    out["det_ids"] = oid
+    out["dets_uc"] = O.get_gaussian_boxes(onet, thresh)[:, -4:]
+    rn.close()
+    np.savez_compressed(os.path.join(GOLD, f"{name}.npz"), **out)
+    print(f"{name}.npz: layers {rn.n}, dets {len(dets)} at thresh {thresh:.6f}")
+
+
 def main():
     assert reflib.available("canon"), "build oracle/_ref first: make -C oracle ref"
     os.makedirs(GOLD, exist_ok=True)
@@ -257,6 +297,7 @@ def main():
     gen_extra()
     gen_map()
     gen_grads()
+    gen_gaussian()
 
 
 def gen_train(name="yolov4-tiny", B=2):
@@ -637,6 +678,8 @@ def gen_map(name="yolov4-tiny", K=4):
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "map":
         gen_map()
+    elif len(sys.argv) > 1 and sys.argv[1] == "gaussian":
+        gen_gaussian()
     elif len(sys.argv) > 1 and sys.argv[1] == "grads":
         gen_grads()
     elif len(sys.argv) > 1 and sys.argv[1] == "train_big":
