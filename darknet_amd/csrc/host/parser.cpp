@@ -103,10 +103,10 @@ static void ParseNetOptions(Section& o, Network* net)
   net->adam = FindOptionIntQuiet(o, "adam", 0);
   if (net->adam)
   {
-    // blas_kernels.cu:99-134 (adam_update_gpu) has no twin here yet: refuse instead of silently
-    // training with SGD + momentum
-    (void)FindOption(o, "B1"); (void)FindOption(o, "B2"); (void)FindOption(o, "eps");
-    error("adam=1 is not supported by the HIP path (only SGD with momentum); remove adam from [net]");
+    // parser.cpp:995-1000
+    net->B1 = FindOptionFloat(o, "B1", .9f);
+    net->B2 = FindOptionFloat(o, "B2", .999f);
+    net->eps = FindOptionFloat(o, "eps", .000001f);
   }
   net->loss_scale = FindOptionFloatQuiet(o, "loss_scale", 1);
   net->power = FindOptionFloatQuiet(o, "power", 4);
@@ -156,6 +156,22 @@ static void ParseConv(layer* l, Section& o, SizeParams params)
     error("share_index is outside the supported hot path");
   FillConvLayer(l, params.batch, params.h, params.w, params.c, n, groups, size, stride_x, stride_y,
       dilation, padding, activation, batch_normalize, params.index, params.train);
+  if (params.net->adam && params.train && dk_gpu_enabled())
+  {
+    // convolutional_layer.cpp:589-620, parser.cpp:236-241: first / second moments of every trained tensor, zeroed
+    l->adam = 1;
+    l->B1 = params.net->B1; l->B2 = params.net->B2; l->eps = params.net->eps;
+    l->m_gpu = cuda_make_array(nullptr, l->nweights);
+    l->v_gpu = cuda_make_array(nullptr, l->nweights);
+    l->bias_m_gpu = cuda_make_array(nullptr, n);
+    l->bias_v_gpu = cuda_make_array(nullptr, n);
+    l->scale_m_gpu = cuda_make_array(nullptr, n);
+    l->scale_v_gpu = cuda_make_array(nullptr, n);
+    for (float* q : {l->m_gpu, l->v_gpu})
+      CHECK_HIP(hipMemsetAsync(q, 0, (size_t)l->nweights * sizeof(float), get_cuda_stream()));
+    for (float* q : {l->bias_m_gpu, l->bias_v_gpu, l->scale_m_gpu, l->scale_v_gpu})
+      CHECK_HIP(hipMemsetAsync(q, 0, (size_t)n * sizeof(float), get_cuda_stream()));
+  }
 }
 
 static int* parse_int_list(const char* a, int* num)

@@ -119,6 +119,18 @@ void UpdateConvolutionalLayerGpu(layer* l, int batch, float learning_rate_init, 
     if (l->scale_updates_gpu)
       dk_scal(l->n, 1.0f / loss_scale, l->scale_updates_gpu, st);
   }
+  if (l->adam)
+  {
+    // convolutional_kernels.cu:884-898: the same adam_update_gpu for weights, biases and scales (decay included)
+    if (dk_adam_update(l->weights_gpu, l->weight_updates_gpu, l->m_gpu, l->v_gpu, l->B1, l->B2, l->eps, decay, lr,
+            l->nweights, batch, l->t, st) ||
+        dk_adam_update(l->biases_gpu, l->bias_updates_gpu, l->bias_m_gpu, l->bias_v_gpu, l->B1, l->B2, l->eps, decay,
+            lr, l->n, batch, l->t, st) ||
+        (l->scales_gpu && dk_adam_update(l->scales_gpu, l->scale_updates_gpu, l->scale_m_gpu, l->scale_v_gpu, l->B1,
+                              l->B2, l->eps, decay, lr, l->n, batch, l->t, st)))
+      error("dk_adam_update failed");
+    return;
+  }
   dk_sgd_update(l->weights_gpu, l->weight_updates_gpu, l->nweights, batch, lr, momentum, decay, 1, st);
   dk_sgd_update(l->biases_gpu, l->bias_updates_gpu, l->n, batch, lr, momentum, decay, 0, st);
   if (l->scales_gpu)
@@ -336,7 +348,7 @@ extern "C" LIB_API size_t DkGradBucketSize(Network* net);
 // train_only_bn, dont_update) and loss_scale is 1; rebuilt when gradient pointers move.
 static bool sgd_plan_usable(Network* net)
 {
-  if (net->loss_scale != 1.0f)
+  if (net->loss_scale != 1.0f || net->adam)
     return false;
   for (int i = 0; i < net->n; ++i)
   {
@@ -406,6 +418,7 @@ void UpdateNetworkGpu(Network* net)
   for (int i = 0; i < net->n; ++i)
   {
     layer* l = &net->layers[i];
+    l->t = iter;   // network_kernels.cu:229 (adam's bias-correction exponent)
     if (l->burnin_update && (l->burnin_update * net->burn_in > iter))
       continue;
     if (l->train_only_bn)

@@ -623,6 +623,54 @@ __global__ void transpose_w_kernel(const float* __restrict__ w, float* __restric
 }
 }  // namespace
 
+// adam_update_gpu (src/blas_kernels.cu:99-134) in one pass, the reference's seven launches
+// (scal m, scal v, axpy decay, axpy m, mul d, axpy v, adam_kernel, fill d) per element in the same order:
+//   m *= B1; v *= B2; d += (-decay*batch)*w; m += (1-B1)*d; d *= d; v += (1-B2)*d;
+//   w += rate * (m / (1 - B1^t)) / (sqrt(v / (1 - B2^t)) + eps); d = 0
+// Like the reference's function it applies the decay term to whatever tensor it is given (biases and scales too).
+namespace
+{
+__global__ void adam_update_kernel(float* __restrict__ w, float* __restrict__ d, float* __restrict__ m,
+    float* __restrict__ v, float B1, float B2, float eps, float decay_batch, float rate, float one_b1, float one_b2,
+    float c1, float c2, size_t n)
+{
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+  {
+    float mi = m[i] * B1;
+    float vi = v[i] * B2;
+    const float wi = w[i];
+    float di = d[i];
+    di = di + decay_batch * wi;
+    mi = mi + one_b1 * di;
+    di = di * di;
+    vi = vi + one_b2 * di;
+    const float mhat = mi / c1;
+    const float vhat = vi / c2;
+    w[i] = wi + rate * mhat / (sqrtf(vhat) + eps);
+    m[i] = mi;
+    v[i] = vi;
+    d[i] = 0.f;
+  }
+}
+}  // namespace
+
+extern "C" int dk_adam_update(float* w, float* d, float* m, float* v, float B1, float B2, float eps, float decay,
+    float rate, size_t n, int batch, int t, void* stream)
+{
+  if (n == 0)
+    return 0;
+  if (!w || !d || !m || !v)
+  {
+    fprintf(stderr, "dk_adam_update: null pointer\n");
+    return 1;
+  }
+  const float c1 = 1.f - powf(B1, (float)t), c2 = 1.f - powf(B2, (float)t);   // adam_kernel: 1.f - powf(B, t)
+  hipLaunchKernelGGL(adam_update_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), w, d, m, v, B1, B2, eps,
+      -decay * batch, rate, 1 - B1, 1 - B2, c1, c2, n);
+  CHECK_HIP(hipPeekAtLastError());
+  return 0;
+}
+
 extern "C" int dk_bn_forward_train(const float* raw, float* x_save, float* x_norm, float* act_in,
     float* out, float* mean, float* variance, float* rolling_mean, float* rolling_variance,
     const float* scales, const float* biases, int batch, int filters, int spatial, int activation,

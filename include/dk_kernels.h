@@ -232,6 +232,9 @@ DK_API int dk_upsample_backward(const float* delta, int w, int h, int c, int bat
  * tensor, fused: wu += -decay*batch*w (if use_decay); w += (lr/batch)*wu; wu *= momentum. */
 DK_API int dk_sgd_update(float* weights, float* weight_updates, size_t n, int batch,
     float learning_rate, float momentum, float decay, int use_decay, void* stream);
+/* adam_update_gpu (src/blas_kernels.cu:120-134) fused: moments m, v updated in place, d zeroed; t = iteration */
+DK_API int dk_adam_update(float* w, float* d, float* m, float* v, float B1, float B2, float eps, float decay,
+    float rate, size_t n, int batch, int t, void* stream);
 
 /* ---- sibling-cfg layer kinds ----------------------------------- */
 /* ForwardAvgpoolLayerGpu / BackwardAvgpoolLayerGpu, src/avgpool_layer_kernels.cu:9-62

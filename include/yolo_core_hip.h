@@ -220,6 +220,11 @@ struct layer
   float *scales_gpu, *scale_updates_gpu;
   float *output_gpu, *activation_input_gpu, *delta_gpu;
 
+  /* adam (convolutional_layer.cpp:589-620): per-tensor first / second moments, iteration counter */
+  int adam, t;
+  float B1, B2, eps;
+  float *m_gpu, *v_gpu, *bias_m_gpu, *bias_v_gpu, *scale_m_gpu, *scale_v_gpu;
+
   /* MI355X-native additions */
   int fused_into_prev;   /* shortcut folded into the previous conv's epilogue */
   int fuse_residual_from; /* conv: layer index whose output is added in the epilogue, or -1 */
@@ -265,6 +270,7 @@ struct Network
   int burn_in;
   int cudnn_half;
   int adam;
+  float B1, B2, eps; /* adam */
   int inputs, outputs, truths;
   int h, w, c;
   int curr_subdiv;

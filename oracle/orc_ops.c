@@ -1178,3 +1178,27 @@ int orc_gaussian_yolo_detections(const float* output, int b, int lw, int lh, int
     }
   return count;
 }
+
+
+/* adam_update_gpu + adam_kernel, src/blas_kernels.cu:99-134 (the reference has NO CPU adam: this restates its
+ * GPU launch sequence one launch at a time; the CUDA build contracts a*b+c into FMAs, here every product is
+ * rounded -- "parity unpinned" for this function, the HIP kernel is checked against it as written). */
+void orc_adam_update(float* w, float* d, float* m, float* v, float B1, float B2, float eps, float decay, float rate,
+    int n, int batch, int t)
+{
+  for (int i = 0; i < n; ++i) m[i] *= B1;                       /* scal_ongpu(n, B1, m) */
+  for (int i = 0; i < n; ++i) v[i] *= B2;                       /* scal_ongpu(n, B2, v) */
+  const float db = -decay * batch;
+  for (int i = 0; i < n; ++i) d[i] += db * w[i];                /* axpy_ongpu(n, -decay*batch, w, d) */
+  const float ob1 = 1 - B1, ob2 = 1 - B2;
+  for (int i = 0; i < n; ++i) m[i] += ob1 * d[i];               /* axpy_ongpu(n, 1-B1, d, m) */
+  for (int i = 0; i < n; ++i) d[i] *= d[i];                     /* mul_ongpu(n, d, d) */
+  for (int i = 0; i < n; ++i) v[i] += ob2 * d[i];               /* axpy_ongpu(n, 1-B2, d, v) */
+  for (int i = 0; i < n; ++i)                                   /* adam_kernel */
+  {
+    float mhat = m[i] / (1.f - powf(B1, t));
+    float vhat = v[i] / (1.f - powf(B2, t));
+    w[i] = w[i] + rate * mhat / (sqrtf(vhat) + eps);
+  }
+  for (int i = 0; i < n; ++i) d[i] = 0;                         /* fill_ongpu(n, 0, d) */
+}

@@ -678,3 +678,62 @@ def test_c4_yolov4_608_b8_train_step_vs_reference_golden(gpu, tmp_path):
     assert float(np.median([d for d, _, _ in devs])) < 3e-2 and worst_norm < 0.25, devs[:6]
     print("C4 gradients vs the reference: worst L2-norm deviation %.3g" % worst_norm)
     net.close()
+
+
+def test_adam_update_vs_oracle(gpu, tmp_path):
+    """adam=1 (src/blas_kernels.cu:99-134, convolutional_kernels.cu:884-898; the reference has no CPU adam, so the
+    oracle restates its GPU launch sequence: "parity unpinned", see oracle/orc_ops.c).  (1) the fused kernel on
+    random tensors over three iterations vs the oracle; (2) a yolov4-tiny net with adam=1: one train step's
+    weights == the oracle's update applied to the gradients the step produced."""
+    L = gpu.lib()
+    L.dk_adam_update.argtypes = [VP, VP, VP, VP] + [C.c_float] * 5 + [C.c_size_t, C.c_int, C.c_int, VP]
+    L.dk_adam_update.restype = C.c_int
+    OL = O.lib()
+    OL.orc_adam_update.argtypes = [C.POINTER(C.c_float)] * 4 + [C.c_float] * 5 + [C.c_int] * 3
+    OL.orc_adam_update.restype = None
+    rng = np.random.default_rng(7)
+    n = 100003
+    w = rng.normal(0, .1, n).astype(np.float32)
+    m = np.zeros(n, np.float32); v = np.zeros(n, np.float32)
+    dw, dm, dv = gpu.DeviceArray(w), gpu.DeviceArray(m), gpu.DeviceArray(v)
+    for t in (1, 2, 3):
+        d = rng.normal(0, 1, n).astype(np.float32)
+        dd = gpu.DeviceArray(d)
+        assert L.dk_adam_update(dw.ptr, dd.ptr, dm.ptr, dv.ptr, .9, .999, 1e-6, 5e-4, 1e-3, n, 64, t, None) == 0
+        OL.orc_adam_update(O.fptr(w), O.fptr(d), O.fptr(m), O.fptr(v), .9, .999, 1e-6, 5e-4, 1e-3, n, 64, t)
+        assert not dd.numpy().any(), "the gradient buffer must be zeroed by the update"
+        util.assert_close(dm.numpy(), m, "adam m, t=%d" % t, rel=1e-6, atol_rms=1e-7)
+        util.assert_close(dv.numpy(), v, "adam v, t=%d" % t, rel=1e-6, atol_rms=1e-7)
+        util.assert_close(dw.numpy(), w, "adam w, t=%d" % t, rel=2e-6, atol_rms=1e-7)
+    # ---- net level
+    g, cfg, wpath, x = train_fixture(tmp_path)
+    cfg2 = str(tmp_path / "adam.cfg")
+    open(cfg2, "w").write(open(cfg).read().replace("momentum=0.9", "momentum=0.9\nadam=1\nB1=0.9\nB2=0.999\neps=0.000001"))
+    for fn, at, rt in (("TrainNetworkDatum", [VP, VP, VP], C.c_float), ("UpdateNetworkGpu", [VP], None),
+                       ("DkAdvanceIteration", [VP], None), ("DkSetMaxIter", [VP, C.c_int], None),
+                       ("GetCurrLr", [VP], C.c_float),
+                       ("DkLayerPull", [VP, C.c_int, C.c_int, VP, C.c_size_t], C.c_long)):
+        getattr(L, fn).argtypes = at
+        getattr(L, fn).restype = rt
+    net = netutil.DkNet(gpu, cfg2, wpath, train=True)
+    L.DkSetMaxIter(net.p, 1000)
+    truth = np.ascontiguousarray(g["truth"])
+    xin = np.ascontiguousarray(x)
+    L.TrainNetworkDatum(net.p, xin.ctypes.data, truth.ctypes.data)
+
+    def pull(i, which, cnt):
+        out = np.empty(cnt, np.float32)
+        assert L.DkLayerPull(net.p, i, which, out.ctypes.data, cnt) == cnt
+        return out
+    convs = [i for i in range(net.n) if net.info(i)["type"] == O.CONVOLUTIONAL]
+    before = {i: (pull(i, 1, net.info(i)["nweights"]), pull(i, 7, net.info(i)["nweights"])) for i in convs[:6]}
+    L.DkAdvanceIteration(net.p)       # curr_iter = 1 -> t = 1
+    lr = L.GetCurrLr(net.p)
+    L.UpdateNetworkGpu(net.p)
+    B = net.batch                     # subdivisions = 1 in the fixture cfg
+    for i, (w0, g0) in before.items():
+        w1 = w0.copy(); d = g0.copy(); m = np.zeros_like(w0); v = np.zeros_like(w0)
+        OL.orc_adam_update(O.fptr(w1), O.fptr(d), O.fptr(m), O.fptr(v), .9, .999, 1e-6, 5e-4, lr, w1.size, B, 1)
+        util.assert_close(pull(i, 1, w0.size), w1, "adam net step, conv %d weights" % i, rel=2e-6, atol_rms=1e-7)
+        assert not pull(i, 7, w0.size).any()
+    net.close()
