@@ -276,16 +276,34 @@ void init_cpu(void) {}
 
 
 // ------------------------------------------------------------------ [Gaussian_yolo]
-// Inference and the pass-through backward of the reference's Gaussian YOLOv3 head
-// (src/gaussian_yolo_layer.cpp).  Its training loss (delta_gaussian_yolo_box :195-405, host code in the
-// reference too) is NOT built: a train-mode forward fails loudly instead of producing wrong deltas.
+// The reference's Gaussian YOLOv3 head (src/gaussian_yolo_layer.cpp): decode on the device; in train mode the
+// head is pulled, the host loss (DkGaussianYoloLossHost, yolo_loss.cpp -- host code in the reference too, :968-995)
+// fills the delta and the cost, and the delta is pushed back.  Synchronous, like the reference.
+extern "C" float DkGaussianYoloLossHost(const layer* l, int net_w, int net_h, float* out, const float* truth, float* delta);
+
 void ForwardGaussianYoloLayerGpu(layer* l, NetworkState state)
 {
   if (dk_gaussian_yolo_forward(state.input, l->output_gpu, l->batch, l->w, l->h, l->n, l->classes, l->scale_x_y,
           get_cuda_stream()))
     error("ForwardGaussianYoloLayerGpu failed");
-  if (state.train && !l->onlyforward)
-    error("[Gaussian_yolo]: the training loss (src/gaussian_yolo_layer.cpp:195-405) is out of scope; inference only");
+  if (!state.train || l->onlyforward)
+    return;
+  const size_t total = (size_t)l->batch * l->outputs;
+  if (l->injected_delta)
+  {
+    cuda_push_array(l->delta_gpu, l->injected_delta, total);
+    return;
+  }
+  if (!state.net->truth)
+    error("[Gaussian_yolo] loss: no truth supplied (TrainNetworkDatum(net, x, y) with y != NULL)");
+  if (!l->delta)
+  {
+    l->delta = cuda_make_array_pinned(nullptr, total);
+    l->delta_pinned = 1;
+  }
+  cuda_pull_array(l->output_gpu, l->output, total);   // synchronises the stream
+  *(l->cost) = DkGaussianYoloLossHost(l, state.net->w, state.net->h, l->output, state.net->truth, l->delta);
+  cuda_push_array(l->delta_gpu, l->delta, total);
 }
 
 // BackwardGaussianYoloLayerGpu, src/gaussian_yolo_layer.cpp:997-1000

@@ -265,7 +265,7 @@ static void ParseGaussianYolo(layer* l, Section& o, SizeParams params)
   l->label_smooth_eps = FindOptionFloatQuiet(o, "label_smooth_eps", 0.0f);
   l->scale_x_y = FindOptionFloatQuiet(o, "scale_x_y", 1);
   l->max_delta = FindOptionFloatQuiet(o, "max_delta", FLT_MAX);
-  (void)FindOptionFloatQuiet(o, "uc_normalizer", 1.0f);
+  l->uc_normalizer = FindOptionFloatQuiet(o, "uc_normalizer", 1.0f);
   l->iou_normalizer = FindOptionFloatQuiet(o, "iou_normalizer", 0.75);
   l->cls_normalizer = FindOptionFloatQuiet(o, "cls_normalizer", 1);
   const char* iou_loss = FindOptionStrQuiet(o, "iou_loss", "mse");

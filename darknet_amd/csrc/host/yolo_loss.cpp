@@ -590,3 +590,306 @@ extern "C" LIB_API float DkYoloLossHost(const layer* l, int net_w, int net_h, fl
   }
   return cost;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// [Gaussian_yolo] training delta / cost: own restatement of ForwardGaussianYoloLayer's
+// train branch (src/gaussian_yolo_layer.cpp:518-851) with delta_gaussian_yolo_box :195-405,
+// AveragesGaussianYoloDeltas :407-428, DeltaGaussianYoloClass :430-461, CompareGaussianYoloClass :463-475 and
+// GetGaussianYoloBox :151-177.  Host code in the reference too (its GPU build pulls the head, runs this and
+// pushes the delta: :968-995).  Pinned BIT-EXACTLY against the real reference: tests/golden/gaussianloss.npz.
+// counters_per_class and map= are not supported by the parser here (classes_multipliers == NULL, no map).
+namespace
+{
+inline int gentry(const layer* l, int b, int location, int e)
+{
+  const int n = location / (l->w * l->h);
+  const int loc = location % (l->w * l->h);
+  return b * l->outputs + n * l->w * l->h * (8 + l->classes + 1) + e * l->w * l->h + loc;
+}
+
+inline Box gaussian_box(const float* x, const float* biases, int a, int index, int i, int j, int lw, int lh,
+    int w, int h, int stride, YOLO_POINT yp)
+{
+  Box b;
+  b.w = expf(x[index + 4 * stride]) * biases[2 * a] / w;
+  b.h = expf(x[index + 6 * stride]) * biases[2 * a + 1] / h;
+  b.x = (i + x[index + 0 * stride]) / lw;
+  b.y = (j + x[index + 2 * stride]) / lh;
+  if (yp == YOLO_LEFT_TOP)
+  {
+    b.x = (i + x[index + 0 * stride]) / lw + b.w / 2;
+    b.y = (j + x[index + 2 * stride]) / lh + b.h / 2;
+  }
+  else if (yp == YOLO_RIGHT_BOTTOM)
+  {
+    b.x = (i + x[index + 0 * stride]) / lw - b.w / 2;
+    b.y = (j + x[index + 2 * stride]) / lh - b.h / 2;
+  }
+  return b;
+}
+
+// one coordinate of the negative-log-likelihood gradient: (mu gradient, sigma gradient) for the residual d and
+// the predicted sigma, in the reference's mixed float / double evaluation
+struct NllGrad
+{
+  float mu, sigma;
+};
+inline NllGrad nll_grad(float d, float sigma, float scale)
+{
+  const float sigma_const = 0.3;
+  const float epsi = pow(10, -9);
+  const float in_exp = d / sigma;
+  const float in_exp_2 = pow((double)in_exp, 2.0);   // std::pow(float, int) promotes to double
+  const float normal_dist = exp(in_exp_2 * (-1. / 2.)) / (sqrt(M_PI * 2.0) * (sigma + sigma_const));
+  const float temp = (1. / 2.) * 1. / (normal_dist + epsi) * normal_dist * scale;
+  NllGrad g;
+  g.mu = temp * in_exp * (1. / sigma);
+  g.sigma = temp * (in_exp_2 / sigma - 1. / (sigma + sigma_const));
+  return g;
+}
+
+// delta_gaussian_yolo_box (accumulate = 1 at every call site); returns the IoU it reports
+float gaussian_box_delta(const Box& truth, const float* x, const float* biases, int a, int index, int i, int j, int lw,
+    int lh, int w, int h, float* delta, float scale, int stride, float iou_normalizer, IOU_LOSS iou_loss,
+    float uc_normalizer, YOLO_POINT yp, float max_delta)
+{
+  Box pred = gaussian_box(x, biases, a, index, i, j, lw, lh, w, h, stride, yp);
+  float iou = Box::Iou(pred, truth);
+  const float giou = giou_of(pred, truth);
+  if (pred.w == 0)
+    pred.w = 1.0;
+  if (pred.h == 0)
+    pred.h = 1.0;
+  float tx = (truth.x * lw - i);
+  float ty = (truth.y * lh - j);
+  const float tw = logf(truth.w * w / biases[2 * a]);
+  const float th = logf(truth.h * h / biases[2 * a + 1]);
+  if (yp == YOLO_LEFT_TOP)
+  {
+    tx = ((truth.x - truth.w / 2) * lw - i);
+    ty = ((truth.y - truth.h / 2) * lh - j);
+  }
+  else if (yp == YOLO_RIGHT_BOTTOM)
+  {
+    tx = ((truth.x + truth.w / 2) * lw - i);
+    ty = ((truth.y + truth.h / 2) * lh - j);
+  }
+  const NllGrad gx = nll_grad(tx - x[index + 0 * stride], x[index + 1 * stride], scale);
+  const NllGrad gy = nll_grad(ty - x[index + 2 * stride], x[index + 3 * stride], scale);
+  const NllGrad gw = nll_grad(tw - x[index + 4 * stride], x[index + 5 * stride], scale);
+  const NllGrad gh = nll_grad(th - x[index + 6 * stride], x[index + 7 * stride], scale);
+  float d_mu[4] = {gx.mu, gy.mu, gw.mu, gh.mu};
+  float d_sg[4] = {gx.sigma, gy.sigma, gw.sigma, gh.sigma};
+  if (iou_loss != MSE)
+  {
+    iou = giou;
+    const BoxGrad g = iou_gradient(pred, truth, iou_loss);
+    float dx = g.dx, dy = g.dy, dw = g.dw, dh = g.dh;
+    if (yp == YOLO_LEFT_TOP)
+    {
+      dx = dx - dw / 2;
+      dy = dy - dh / 2;
+    }
+    else if (yp == YOLO_RIGHT_BOTTOM)
+    {
+      dx = dx + dw / 2;
+      dy = dy + dh / 2;
+    }
+    dw *= expf(x[index + 4 * stride]);
+    dh *= expf(x[index + 6 * stride]);
+    d_mu[0] = dx; d_mu[1] = dy; d_mu[2] = dw; d_mu[3] = dh;
+  }
+  for (int k = 0; k < 4; ++k)
+  {
+    d_mu[k] *= iou_normalizer;
+    d_sg[k] *= uc_normalizer;
+  }
+  for (int k = 0; k < 4; ++k)
+  {
+    d_mu[k] = zero_if_not_finite(d_mu[k]);
+    d_sg[k] = zero_if_not_finite(d_sg[k]);
+  }
+  if (max_delta != FLT_MAX)
+    for (int k = 0; k < 4; ++k)
+    {
+      d_mu[k] = clamp_abs(d_mu[k], max_delta);
+      d_sg[k] = clamp_abs(d_sg[k], max_delta);
+    }
+  for (int k = 0; k < 4; ++k)
+  {
+    delta[index + (2 * k) * stride] += d_mu[k];
+    delta[index + (2 * k + 1) * stride] += d_sg[k];
+  }
+  return iou;
+}
+
+// DeltaGaussianYoloClass
+void gaussian_class_delta(const float* output, float* delta, int index, int class_id, int classes, int stride,
+    float label_smooth_eps)
+{
+  if (delta[index])
+  {
+    float y_true = 1;
+    if (label_smooth_eps)
+      y_true = y_true * (1 - label_smooth_eps) + 0.5 * label_smooth_eps;
+    delta[index + stride * class_id] = y_true - output[index + stride * class_id];
+    return;
+  }
+  for (int n = 0; n < classes; ++n)
+  {
+    float y_true = ((n == class_id) ? 1 : 0);
+    if (label_smooth_eps)
+      y_true = y_true * (1 - label_smooth_eps) + 0.5 * label_smooth_eps;
+    delta[index + stride * n] = y_true - output[index + stride * n];
+  }
+}
+
+inline int mask_index(const int* mask, int val, int n)
+{
+  for (int i = 0; i < n; ++i)
+    if (mask[i] == val)
+      return i;
+  return -1;
+}
+}  // namespace
+
+extern "C" LIB_API float DkGaussianYoloLossHost(const layer* l, int net_w, int net_h, float* out, const float* truth_all,
+    float* delta)
+{
+  const int stride = l->w * l->h;
+  const size_t total = (size_t)l->batch * l->outputs;
+  memset(delta, 0, total * sizeof(float));
+  for (int b = 0; b < l->batch; ++b)
+  {
+    const float* tb = truth_all + (size_t)b * l->truths;
+    // ---- every predictor: no-object gradient unless it overlaps a truth of a confidently predicted class
+    for (int j = 0; j < l->h; ++j)
+      for (int i = 0; i < l->w; ++i)
+        for (int n = 0; n < l->n; ++n)
+        {
+          const int loc = n * stride + j * l->w + i;
+          const int box_index = gentry(l, b, loc, 0);
+          const Box pred = gaussian_box(out, l->biases, l->mask[n], box_index, i, j, l->w, l->h, net_w, net_h, stride,
+              l->yolo_point);
+          float best_match_iou = 0, best_iou = 0;
+          int best_t = 0;
+          const int class_index = gentry(l, b, loc, 9);
+          const int obj_index = gentry(l, b, loc, 8);
+          for (int t = 0; t < l->max_boxes; ++t)
+          {
+            const Box truth{tb[t * 5 + 0], tb[t * 5 + 1], tb[t * 5 + 2], tb[t * 5 + 3]};
+            const int class_id = tb[t * 5 + 4];
+            if (class_id >= l->classes)
+              continue;
+            if (!truth.x)
+              break;
+            int match = 0;   // CompareGaussianYoloClass with conf_thresh 0.25
+            for (int c = 0; c < l->classes; ++c)
+              if (out[class_index + stride * c] > 0.25f)
+              {
+                match = 1;
+                break;
+              }
+            const float iou = Box::Iou(pred, truth);
+            if (iou > best_match_iou && match == 1)
+              best_match_iou = iou;
+            if (iou > best_iou)
+            {
+              best_iou = iou;
+              best_t = t;
+            }
+          }
+          delta[obj_index] = l->cls_normalizer * (0 - out[obj_index]);
+          if (best_match_iou > l->ignore_thresh)
+            delta[obj_index] = 0;
+          if (best_iou > l->truth_thresh)
+          {
+            delta[obj_index] = l->cls_normalizer * (1 - out[obj_index]);
+            const int class_id = tb[best_t * 5 + 4];
+            gaussian_class_delta(out, delta, class_index, class_id, l->classes, stride, l->label_smooth_eps);
+            const Box truth{tb[best_t * 5 + 0], tb[best_t * 5 + 1], tb[best_t * 5 + 2], tb[best_t * 5 + 3]};
+            gaussian_box_delta(truth, out, l->biases, l->mask[n], box_index, i, j, l->w, l->h, net_w, net_h, delta,
+                (2 - truth.w * truth.h), stride, l->iou_normalizer * 1.0f, l->iou_loss, l->uc_normalizer, l->yolo_point,
+                l->max_delta);
+          }
+        }
+    // ---- every truth: its best anchor (and the anchors above iou_thresh) at the truth's cell
+    for (int t = 0; t < l->max_boxes; ++t)
+    {
+      const Box truth{tb[t * 5 + 0], tb[t * 5 + 1], tb[t * 5 + 2], tb[t * 5 + 3]};
+      if (!truth.x)
+        break;
+      float best_iou = 0;
+      int best_n = 0;
+      int i = (truth.x * l->w);
+      int j = (truth.y * l->h);
+      if (l->yolo_point == YOLO_LEFT_TOP)
+      {
+        i = std::min((float)(l->w - 1), std::max(0.f, ((truth.x - truth.w / 2) * l->w)));
+        j = std::min((float)(l->h - 1), std::max(0.f, ((truth.y - truth.h / 2) * l->h)));
+      }
+      else if (l->yolo_point == YOLO_RIGHT_BOTTOM)
+      {
+        i = std::min((float)(l->w - 1), std::max(0.f, ((truth.x + truth.w / 2) * l->w)));
+        j = std::min((float)(l->h - 1), std::max(0.f, ((truth.y + truth.h / 2) * l->h)));
+      }
+      Box truth_shift = truth;
+      truth_shift.x = truth_shift.y = 0;
+      for (int n = 0; n < l->total; ++n)
+      {
+        Box pred{0, 0, l->biases[2 * n] / net_w, l->biases[2 * n + 1] / net_h};
+        const float iou = Box::Iou(pred, truth_shift);
+        if (iou > best_iou)
+        {
+          best_iou = iou;
+          best_n = n;
+        }
+      }
+      const int class_id = tb[t * 5 + 4];
+      auto assign = [&](int anchor, int mask_n) {
+        const int loc = mask_n * stride + j * l->w + i;
+        const int box_index = gentry(l, b, loc, 0);
+        gaussian_box_delta(truth, out, l->biases, anchor, box_index, i, j, l->w, l->h, net_w, net_h, delta,
+            (2 - truth.w * truth.h), stride, l->iou_normalizer * 1.0f, l->iou_loss, l->uc_normalizer, l->yolo_point,
+            l->max_delta);
+        const int obj_index = gentry(l, b, loc, 8);
+        delta[obj_index] = 1.0f * l->cls_normalizer * (1 - out[obj_index]);
+        gaussian_class_delta(out, delta, gentry(l, b, loc, 9), class_id, l->classes, stride, l->label_smooth_eps);
+      };
+      const int mask_n = mask_index(l->mask, best_n, l->n);
+      if (mask_n >= 0)
+        assign(best_n, mask_n);
+      for (int n = 0; n < l->total; ++n)
+      {
+        const int mn = mask_index(l->mask, n, l->n);
+        if (mn >= 0 && n != best_n && l->iou_thresh < 1.0f)
+        {
+          Box pred{0, 0, l->biases[2 * n] / net_w, l->biases[2 * n + 1] / net_h};
+          const float iou = iou_kind(pred, truth_shift, l->iou_thresh_kind);
+          if (iou > l->iou_thresh)
+            assign(n, mn);
+        }
+      }
+    }
+    // ---- AveragesGaussianYoloDeltas over every predictor of the image
+    for (int j = 0; j < l->h; ++j)
+      for (int i = 0; i < l->w; ++i)
+        for (int n = 0; n < l->n; ++n)
+        {
+          const int loc = n * stride + j * l->w + i;
+          const int box_index = gentry(l, b, loc, 0), class_index = gentry(l, b, loc, 9);
+          int classes_in_one_box = 0;
+          for (int c = 0; c < l->classes; ++c)
+            if (delta[class_index + stride * c] > 0)
+              classes_in_one_box++;
+          if (classes_in_one_box > 0)
+            for (int e = 0; e < 8; ++e) delta[box_index + e * stride] /= classes_in_one_box;
+        }
+  }
+  // *(l->cost) = pow(mag_array(l->delta, n), 2): float sum of squares, sqrtf, squared in double
+  float sum = 0;
+  for (size_t k = 0; k < total; ++k) sum += delta[k] * delta[k];
+  const float mag = sqrtf(sum);
+  return (float)pow((double)mag, 2.0);
+}

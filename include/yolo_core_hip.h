@@ -186,6 +186,7 @@ struct layer
   IOU_LOSS iou_loss, iou_thresh_kind;
   NMS_KIND nms_kind;
   YOLO_POINT yolo_point; /* [Gaussian_yolo]: which point of the box the head predicts */
+  float uc_normalizer;   /* [Gaussian_yolo]: weight of the uncertainty gradients */
   int* map;
 
   /* per-layer common keys, src/parser.cpp:1361-1369 */
@@ -484,6 +485,8 @@ LIB_API void ForwardUpsampleLayerGpu(layer* l, NetworkState state);
 LIB_API void ForwardYoloLayerGpu(layer* l, NetworkState state);
 LIB_API void ForwardGaussianYoloLayerGpu(layer* l, NetworkState state);   /* inference; src/gaussian_yolo_layer.cpp:934 */
 LIB_API void BackwardGaussianYoloLayerGpu(layer* l, NetworkState state);
+/* host loss of the Gaussian head (src/gaussian_yolo_layer.cpp:518-851): fills delta, returns the cost */
+LIB_API float DkGaussianYoloLossHost(const layer* l, int net_w, int net_h, float* out, const float* truth, float* delta);
 LIB_API int YoloNumDetections(layer const* l, float thresh);
 LIB_API int GetYoloDetections(layer const* l, int net_w, int net_h, float thresh, Detection* dets);
 

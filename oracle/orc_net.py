@@ -576,6 +576,8 @@ def forward_train(net, x):
             L.orc_upsample_forward(fptr(inp), l.w, l.h, l.c, B, l.stride, F(l.scale), fptr(out))
         elif l.type == YOLO:
             L.orc_yolo_forward(fptr(inp), fptr(out), B, l.w, l.h, l.n, l.classes, F(l.scale_x_y))
+        elif l.type == GAUSSIAN_YOLO:
+            L.orc_gaussian_yolo_forward(fptr(inp), fptr(out), B, l.w, l.h, l.n, l.classes, F(l.scale_x_y))
         else:
             out = _forward_extra(L, net, l, inp, out, train=True)
         l.output = out

@@ -211,3 +211,44 @@ def test_gaussian_yolo_heads_vs_reference_golden(gpu, tmp_path):
             assert abs(len(ids1) - len(oids)) <= (~clear).sum()
     L.DkSetPullHeads(1)
     net.close()
+
+
+def test_gaussian_yolo_train_step_vs_reference_golden(gpu, tmp_path):
+    """One train step of cfg/gaussian-test.cfg at batch 2 (device forward with batch statistics, the Gaussian head
+    pulled, host loss, delta pushed, backward): the network cost and both heads' deltas vs the REAL reference's
+    (tests/golden/gaussianloss.npz).  The host loss itself is bit-exact (tests/test_yolo_loss_cpu.py); here its
+    input comes from the HIP train forward, so values agree within the train-mode tolerance."""
+    g = np.load(os.path.join(GOLD, "gaussianloss.npz"))
+    B = int(g["batch"])
+    root = os.path.normpath(os.path.join(os.path.dirname(GOLD), ".."))
+    cfg = str(tmp_path / "g.cfg")
+    open(cfg, "w").write(open(os.path.join(root, "cfg", "gaussian-test.cfg")).read().replace("batch=1", "batch=%d" % B, 1))
+    onet = O.parse_cfg(cfg)
+    w = str(tmp_path / "w.weights")
+    synth.write_weights_layers(w, synth.weight_layers_of(onet), seed=2024)
+    x = np.ascontiguousarray(synth.make_input(B, onet.c, onet.h, onet.w, seed=12345))
+    truth = np.ascontiguousarray(g["truth"])
+    L = gpu.lib()
+    bind(L)
+    net = netutil.DkNet(gpu, cfg, w, train=True)
+    assert net.batch == B
+    L.DkSetMaxIter(net.p, 100)
+    cost = L.TrainNetworkDatum(net.p, x.ctypes.data, truth.ctypes.data)
+    heads = [i for i in range(net.n) if net.info(i)["type"] == O.GAUSSIAN_YOLO]
+    want = float(np.mean([g["cost_%d" % i] for i in heads]))
+    assert abs(cost - want) <= 2e-3 * want, (cost, want)
+    for i in heads:
+        n = B * net.info(i)["outputs"]
+        d = np.empty(n, np.float32)
+        assert L.DkLayerPull(net.p, i, 6, d.ctypes.data, n) == n
+        ref = np.zeros(n, np.float32)
+        ref[g["delta_%d_idx" % i]] = g["delta_%d_val" % i]
+        assert np.setxor1d(np.flatnonzero(d), g["delta_%d_idx" % i]).size <= 0.01 * g["delta_%d_idx" % i].size
+        same = (d != 0) & (ref != 0)
+        util.assert_close(d[same], ref[same], "gaussian head %d deltas" % i, rel=5e-3, atol_rms=util.TRAIN_ATOL_RMS)
+    # the gradient reached the first conv
+    n0 = net.info(0)["nweights"]
+    g0 = np.empty(n0, np.float32)
+    assert L.DkLayerPull(net.p, 0, 7, g0.ctypes.data, n0) == n0
+    assert np.isfinite(g0).all() and np.abs(g0).max() > 0
+    net.close()

@@ -284,6 +284,44 @@ def gen_gaussian():
     print(f"{name}.npz: layers {rn.n}, dets {len(dets)} at thresh {thresh:.6f}")
 
 
+def gen_gaussianloss():
+    """The reference's Gaussian-YOLO loss (ForwardGaussianYoloLayer train branch, host C++) on cfg/gaussian-test.cfg:
+    sparse deltas and cost of both heads for b = 2 with 4 truths/image (first head: mse boxes, second head: giou boxes,
+    iou_thresh, max_delta, label smoothing, uc_normalizer) -> gaussianloss.npz."""
+    name = "gaussian-test"
+    B = 2
+    cfg = "/tmp/_dk_gloss.cfg"
+    open(cfg, "w").write(open(os.path.join(ROOT, "cfg", name + ".cfg")).read().replace("batch=1", "batch=%d" % B, 1))
+    net = O.parse_cfg(cfg)
+    wpath = "/tmp/_dk_gaussian.weights"
+    synth.write_weights_layers(wpath, synth.weight_layers_of(net), seed=2024)
+    x = synth.make_input(B, net.c, net.h, net.w, seed=12345)
+    boxes = [(.3, .4, .2, .3, 1), (.6, .5, .4, .35, 3), (.8, .2, .1, .15, 0), (.5, .5, .9, .8, 2)]
+    truth = np.zeros((B, 90 * 5), np.float32)
+    for b in range(B):
+        for t, box in enumerate(boxes[b:] + boxes[:b]):
+            truth[b, t * 5:(t + 1) * 5] = box
+    rn = reflib.RefNet(cfg, wpath, train=True)
+    assert rn.batch == B
+    rn.L.ref_forward_train(rn.p, fp(x), fp(truth))
+    onet = O.load_network_train(cfg, wpath, None)
+    O.forward_train(onet, x)
+    out = {"truth": truth, "batch": np.int32(B)}
+    for i, l in enumerate(onet.layers):
+        assert np.array_equal(rn.output(i), l.output.ravel()), f"gaussian train forward: oracle != reference at {i}"
+        if l.type != O.GAUSSIAN_YOLO:
+            continue
+        d = rn.arr(i, 6, l.batch * l.outputs)
+        nz = np.flatnonzero(d)
+        out[f"delta_{i}_idx"] = nz.astype(np.int64)
+        out[f"delta_{i}_val"] = d[nz]
+        out[f"cost_{i}"] = np.float32(rn.L.ref_layer_cost(rn.p, i))
+        print("gaussian head", i, "nonzero deltas", nz.size, "cost", rn.L.ref_layer_cost(rn.p, i))
+    rn.close()
+    np.savez_compressed(os.path.join(GOLD, "gaussianloss.npz"), **out)
+    print("gaussianloss.npz")
+
+
 def main():
     assert reflib.available("canon"), "build oracle/_ref first: make -C oracle ref"
     os.makedirs(GOLD, exist_ok=True)
@@ -298,6 +336,7 @@ def main():
     gen_map()
     gen_grads()
     gen_gaussian()
+    gen_gaussianloss()
 
 
 def gen_train(name="yolov4-tiny", B=2):
@@ -680,6 +719,7 @@ if __name__ == "__main__":
         gen_map()
     elif len(sys.argv) > 1 and sys.argv[1] == "gaussian":
         gen_gaussian()
+        gen_gaussianloss()
     elif len(sys.argv) > 1 and sys.argv[1] == "grads":
         gen_grads()
     elif len(sys.argv) > 1 and sys.argv[1] == "train_big":
