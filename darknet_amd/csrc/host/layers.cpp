@@ -683,6 +683,7 @@ void free_layer(layer* l, bool)
     cuda_free(l->dual_weights_gpu); cuda_free(l->dual_biases_gpu);
     cuda_free(l->biases_gpu); cuda_free(l->bias_updates_gpu);
     cuda_free(l->scales_gpu); cuda_free(l->scale_updates_gpu);
+    cuda_free(l->rand_gpu);
     cuda_free(l->m_gpu); cuda_free(l->v_gpu); cuda_free(l->bias_m_gpu); cuda_free(l->bias_v_gpu);
     cuda_free(l->scale_m_gpu); cuda_free(l->scale_v_gpu);
     cuda_free(l->activation_input_gpu);

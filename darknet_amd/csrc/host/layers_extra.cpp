@@ -226,16 +226,32 @@ void BackwardScaleChannelsLayerGpu(layer* l, NetworkState state)
 }
 
 // ------------------------------------------------------------------ [dropout]
-// Inference: identity; the layer aliases its predecessor's buffers exactly as the reference
-// does (parser.cpp:1232-1242).  Training needs the reference's cuRAND stream to be reproduced
-// and is outside the hot path: refused loudly.
+// Inference: identity; the layer aliases its predecessor's buffers exactly as the reference does
+// (parser.cpp:1232-1242).  Training (dropout_layer_kernels.cu / dropout_layer.c:90-120): uniform draws, zero below
+// `probability`, the rest scaled by 1/(1-p), in place; backward applies the same mask to the incoming delta.  The
+// reference's cuRAND / rand() streams cannot be reproduced: the draws are a counter-based hash seeded by
+// (iteration, layer index, call count) -- deterministic per run, statistically the same layer ("parity unpinned").
 static void forward_dropout_gpu(layer* l, NetworkState state)
 {
-  if (state.train)
-    error("[dropout] in train mode is outside the supported hot path (needs the reference's RNG stream)");
-  (void)l;
+  if (!state.train)
+    return;
+  const size_t n = (size_t)l->inputs * l->batch;
+  if (!l->rand_gpu)
+    l->rand_gpu = cuda_make_array(nullptr, n);
+  const unsigned long long seed = ((unsigned long long)(unsigned)state.net->curr_iter << 40) ^
+                                  ((unsigned long long)(unsigned)l->index << 24) ^ (unsigned long long)(l->t++);
+  if (dk_dropout_forward(state.input, l->rand_gpu, n, l->probability, l->scale, seed, get_cuda_stream()))
+    error("forward_dropout_gpu failed");
 }
-static void backward_dropout_gpu(layer*, NetworkState) { error("[dropout] backward is outside the supported hot path"); }
+static void backward_dropout_gpu(layer* l, NetworkState state)
+{
+  if (!state.delta)
+    return;
+  if (!l->rand_gpu)
+    error("[dropout] backward without a train-mode forward");
+  if (dk_dropout_backward(state.delta, l->rand_gpu, (size_t)l->inputs * l->batch, l->probability, l->scale, get_cuda_stream()))
+    error("backward_dropout_gpu failed");
+}
 
 void FillDropoutLayer(layer* l, int batch, int inputs, float probability, int w, int h, int c)
 {

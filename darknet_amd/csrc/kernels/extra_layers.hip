@@ -171,3 +171,66 @@ extern "C" int dk_scale_channels_backward(const float* delta, const float* in, c
         S(stream), delta, in, from, from_delta, in_delta, (size_t)batch * out_c, cs);
   return 0;
 }
+
+
+// ---- [dropout], train mode (src/dropout_layer_kernels.cu: cuda_random + yoloswag420blazeit360noscope; CPU
+// dropout_layer.c:90-104) ------------------------------------------------------------------------------------
+// rand[i] uniform in [0, 1); x[i] = rand[i] < probability ? 0 : x[i] * scale, in place; the backward pass applies the
+// same mask and scale to the delta.  The reference draws from cuRAND (GPU) or rand() (CPU): neither stream can be
+// reproduced, so the draw here is a counter-based hash of (seed, i) -- same distribution, "parity unpinned".
+namespace
+{
+__device__ __forceinline__ float hash_uniform(unsigned long long seed, unsigned long long i)
+{
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ULL * (i + 1);   // splitmix64
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  z = z ^ (z >> 31);
+  return (float)(z >> 40) * (1.0f / 16777216.0f);   // 24 random bits -> [0, 1)
+}
+__global__ void dropout_forward_kernel(float* __restrict__ x, float* __restrict__ rnd, size_t n, float prob, float scale,
+    unsigned long long seed)
+{
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+  {
+    const float r = hash_uniform(seed, i);
+    rnd[i] = r;
+    x[i] = (r < prob) ? 0.f : x[i] * scale;
+  }
+}
+__global__ void dropout_backward_kernel(float* __restrict__ delta, const float* __restrict__ rnd, size_t n, float prob,
+    float scale)
+{
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    delta[i] = (rnd[i] < prob) ? 0.f : delta[i] * scale;
+}
+}  // namespace
+
+extern "C" int dk_dropout_forward(float* x, float* rnd, size_t n, float probability, float scale,
+    unsigned long long seed, void* stream)
+{
+  if (n == 0)
+    return 0;
+  if (!x || !rnd)
+    return 1;
+  unsigned g = (unsigned)((n + 255) / 256);
+  if (g > 65535u) g = 65535u;
+  hipLaunchKernelGGL(dropout_forward_kernel, dim3(g), dim3(256), 0, stream ? (hipStream_t)stream : get_cuda_stream(), x, rnd, n,
+      probability, scale, seed);
+  CHECK_HIP(hipPeekAtLastError());
+  return 0;
+}
+
+extern "C" int dk_dropout_backward(float* delta, const float* rnd, size_t n, float probability, float scale, void* stream)
+{
+  if (n == 0)
+    return 0;
+  if (!delta || !rnd)
+    return 1;
+  unsigned g = (unsigned)((n + 255) / 256);
+  if (g > 65535u) g = 65535u;
+  hipLaunchKernelGGL(dropout_backward_kernel, dim3(g), dim3(256), 0, stream ? (hipStream_t)stream : get_cuda_stream(), delta,
+      rnd, n, probability, scale);
+  CHECK_HIP(hipPeekAtLastError());
+  return 0;
+}

@@ -251,6 +251,11 @@ DK_API int dk_scale_channels_forward(const float* in, const float* from, float* 
     int out_h, int out_w, int scale_wh, int activation, void* stream);
 DK_API int dk_scale_channels_backward(const float* delta, const float* in, const float* from, float* from_delta,
     float* in_delta, int batch, int out_c, int out_h, int out_w, int scale_wh, void* stream);
+/* [dropout] in train mode, in place (dropout_layer_kernels.cu): rnd[i] uniform in [0,1) from a counter-based hash of
+ * (seed, i); x[i] = rnd[i] < probability ? 0 : x[i] * scale; the backward applies the same mask to the delta */
+DK_API int dk_dropout_forward(float* x, float* rnd, size_t n, float probability, float scale, unsigned long long seed,
+    void* stream);
+DK_API int dk_dropout_backward(float* delta, const float* rnd, size_t n, float probability, float scale, void* stream);
 
 /* Profiling hooks used by bench.py (measurement only): when enabled every
  * dk_conv_forward is bracketed by HIP events on its stream; dk_profile_read

@@ -187,6 +187,7 @@ struct layer
   NMS_KIND nms_kind;
   YOLO_POINT yolo_point; /* [Gaussian_yolo]: which point of the box the head predicts */
   float uc_normalizer;   /* [Gaussian_yolo]: weight of the uncertainty gradients */
+  float* rand_gpu;       /* [dropout] train mode: the uniform draws of the last forward (mask of the backward) */
   int* map;
 
   /* per-layer common keys, src/parser.cpp:1361-1369 */

@@ -252,3 +252,62 @@ def test_gaussian_yolo_train_step_vs_reference_golden(gpu, tmp_path):
     assert L.DkLayerPull(net.p, 0, 7, g0.ctypes.data, n0) == n0
     assert np.isfinite(g0).all() and np.abs(g0).max() > 0
     net.close()
+
+
+def test_dropout_train_mode(gpu, tmp_path):
+    """[dropout] with state.train (dropout_layer_kernels.cu): the reference's cuRAND / rand() draws cannot be
+    reproduced ("parity unpinned"), so the layer is checked by what it must do: draws uniform in [0, 1), exactly the
+    elements with draw < p zeroed, the rest scaled by 1/(1-p) bit-exactly, the same mask on the backward delta, a
+    different mask for another seed; and a train step of cfg/se-test.cfg WITH its [dropout] runs to a finite cost."""
+    L = gpu.lib()
+    L.dk_dropout_forward.argtypes = [VP, VP, C.c_size_t, C.c_float, C.c_float, C.c_ulonglong, VP]
+    L.dk_dropout_backward.argtypes = [VP, VP, C.c_size_t, C.c_float, C.c_float, VP]
+    n, p = 1 << 20, 0.3
+    scale = np.float32(1. / (1. - p))
+    rng = np.random.default_rng(0)
+    x = rng.normal(0, 1, n).astype(np.float32)
+    dx, dr = gpu.DeviceArray(x), gpu.DeviceArray(n=n)
+    assert L.dk_dropout_forward(dx.ptr, dr.ptr, n, p, scale, 1234, None) == 0
+    y, r = dx.numpy(), dr.numpy()
+    assert r.min() >= 0 and r.max() < 1
+    drop = r < np.float32(p)
+    assert abs(drop.mean() - p) < 4 * np.sqrt(p * (1 - p) / n), drop.mean()
+    assert abs(r.mean() - 0.5) < 4 * np.sqrt(1 / 12 / n)
+    assert not y[drop].any() and np.array_equal(y[~drop], x[~drop] * scale)
+    d = rng.normal(0, 1, n).astype(np.float32)
+    dd = gpu.DeviceArray(d)
+    assert L.dk_dropout_backward(dd.ptr, dr.ptr, n, p, scale, None) == 0
+    gd = dd.numpy()
+    assert not gd[drop].any() and np.array_equal(gd[~drop], d[~drop] * scale)
+    dx2, dr2 = gpu.DeviceArray(x), gpu.DeviceArray(n=n)
+    L.dk_dropout_forward(dx2.ptr, dr2.ptr, n, p, scale, 1235, None)
+    assert (dr2.numpy() != r).mean() > 0.99, "another seed must give another mask"
+    dx3, dr3 = gpu.DeviceArray(x), gpu.DeviceArray(n=n)
+    L.dk_dropout_forward(dx3.ptr, dr3.ptr, n, p, scale, 1234, None)
+    assert np.array_equal(dr3.numpy(), r), "same seed, same mask"
+    # ---- a train step of the cfg with its [dropout] layer
+    bind(L)
+    inf, _ = synth.se_cfgs(tmp_path)
+    txt = open(inf).read()
+    a = txt.index("\n[batchnorm]\n") + 1          # the reference cannot train a standalone [batchnorm]: drop it
+    txt = txt[:a] + txt[txt.index("[convolutional]", a):]
+    cfg = str(tmp_path / "drop_train.cfg")
+    open(cfg, "w").write(txt.replace("batch=1", "batch=2", 1))
+    onet = O.parse_cfg(cfg)
+    assert any(l.type == O.DROPOUT for l in onet.layers)
+    w = str(tmp_path / "w.weights")
+    synth.write_weights_layers(w, synth.weight_layers_of(onet), seed=2024)
+    net = netutil.DkNet(gpu, cfg, w, train=True)
+    B = net.batch
+    xin = np.ascontiguousarray(synth.make_input(B, onet.c, onet.h, onet.w, seed=5))
+    truth = np.zeros((B, 90 * 5), np.float32)
+    truth[:, :5] = (.4, .5, .3, .3, 1)
+    L.DkSetMaxIter(net.p, 100)
+    cost = L.TrainNetworkDatum(net.p, xin.ctypes.data, truth.ctypes.data)
+    assert np.isfinite(cost) and cost > 0
+    di = [i for i, l in enumerate(onet.layers) if l.type == O.DROPOUT][0]
+    out = net.output(di).ravel()
+    frac = (out == 0).mean()
+    pl = onet.layers[di].probability if hasattr(onet.layers[di], "probability") else None
+    assert frac > 0.05, "the dropout layer did not drop anything in train mode (zero fraction %g)" % frac
+    net.close()
