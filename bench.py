@@ -101,15 +101,19 @@ def main():
     from darknet_amd import netapi
     import synth
 
-    ctx = dkdist.DistCtx(backend="nccl")
+    # DK_BENCH_REHEARSE=1: rehearsal of the N > 1 path on a box with ONE GPU (launcher, rendezvous, sharding,
+    # aggregation): gloo instead of RCCL, every rank on device 0.  Never a measurement.
+    rehearse = bool(os.environ.get("DK_BENCH_REHEARSE"))
+    ctx = dkdist.DistCtx(backend="gloo" if rehearse else "nccl")
     if ctx.world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)"
                          % (args.gpus, ctx.world))
     L = dk.lib()
     if L.CudaGetDeviceCount() < 1:
         raise SystemExit("bench.py: no HIP device visible (there is no CPU fallback)")
-    torch.cuda.set_device(ctx.local_rank)
-    L.cuda_set_device(ctx.local_rank)
+    dev_index = 0 if rehearse else ctx.local_rank
+    torch.cuda.set_device(dev_index)
+    L.cuda_set_device(dev_index)
 
     if args.half:
         L.DkSetHalf.argtypes = [C.c_int]
