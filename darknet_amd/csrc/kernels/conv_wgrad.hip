@@ -55,7 +55,12 @@ __device__ __forceinline__ float ld_buf(__amdgpu_buffer_rsrc_t r, unsigned byte_
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
 }
 
-template <int TM, int TK, bool AVEC>
+// TMAJ: the tap tile is taken from the contraction index re-ordered tap-major, k' = t * C + c (t = kh * size + kw),
+// which the host selects when C is a multiple of the tile width: then ALL taps of a workgroup share one (kh, kw), a
+// thread's padding test is ONE range check per stage, and its 16 gather offsets are `pixel base + constant` (one
+// add each) instead of five VALU operations each -- the kernel spent 5 VALU instructions per MFMA on that
+// (rocprofv3: SQ_INSTS_VALU / SQ_INSTS_MFMA = 5.1, MFMA pipe 48 % busy).  dW keeps the reference's [m][c][kh][kw] layout.
+template <int TM, int TK, bool AVEC, bool TMAJ>
 __global__ void __launch_bounds__(T) conv_wgrad_f32(const WgradArgs p)
 {
   constexpr int BM = 64 * TM, BKO = 64 * TK;
@@ -93,9 +98,18 @@ __global__ void __launch_bounds__(T) conv_wgrad_f32(const WgradArgs p)
   const int ss = p.size * p.size;
   unsigned toff[PB];            // byte offset of the tap inside an image-group, or OOB
   int tsh[PB];                  // 31 - tap: shifts the tap's "outside" bit to the sign position
+  // TMAJ: the workgroup's tap (kh, kw) and first channel
+  const int tm_t = TMAJ ? k0 / p.C : 0, tm_c0 = TMAJ ? k0 - tm_t * p.C : 0;
+  const int tm_kh = tm_t / p.size, tm_kw = tm_t - tm_kh * p.size;
 #pragma unroll
   for (int j = 0; j < PB; ++j)
   {
+    if (TMAJ)
+    {
+      toff[j] = (unsigned)((tm_c0 + r8 + 8 * j) * HW + tm_kh * p.dil * p.W + tm_kw * p.dil) * 4u;
+      tsh[j] = 0;
+      continue;
+    }
     const int k = k0 + r8 + 8 * j;
     const bool ok = k < p.K;
     const int kk = ok ? k : 0;
@@ -146,8 +160,17 @@ __global__ void __launch_bounds__(T) conv_wgrad_f32(const WgradArgs p)
 #pragma unroll
       for (int j = 0; j < PA; ++j) ra[j] = ld_buf(dr, (base + roff[j]) | ((base | roff[j]) & OOB));
     }
-    // col: padding mask of this pixel (bit t set <=> tap t is outside the image)
     const int iy0 = oy * p.stride_y - p.pad, ix0 = ox * p.stride_x - p.pad;
+    if (TMAJ)
+    {
+      // one tap for the whole workgroup: one range check, then `base + constant` per channel
+      const bool in = n < p.N && (unsigned)(iy0 + tm_kh * p.dil) < (unsigned)p.H && (unsigned)(ix0 + tm_kw * p.dil) < (unsigned)p.W;
+      const unsigned xb = in ? (unsigned)((b * p.Ctot + g * p.C) * HW + iy0 * p.W + ix0) * 4u : OOB;
+#pragma unroll
+      for (int j = 0; j < PB; ++j) rb[j] = ld_buf(xr, xb + toff[j]);
+      return;
+    }
+    // col: padding mask of this pixel (bit t set <=> tap t is outside the image)
     unsigned colbits = 0, okbits = 0;
     for (int kw = 0; kw < p.size; ++kw)
       colbits |= ((unsigned)(ix0 + kw * p.dil) < (unsigned)p.W ? 1u : 0u) << kw;
@@ -269,6 +292,9 @@ __global__ void __launch_bounds__(T) conv_wgrad_f32(const WgradArgs p)
 #pragma unroll
   for (int j = 0; j < TK; ++j)
   {
+    // TMAJ accumulates into a tap-major workspace [m][t][c] (consecutive lanes = consecutive addresses: the float
+    // atomics stay coalesced; scattered to [c][kh][kw] directly they ran 2.4x slower); wgrad_fold_kernel adds the
+    // workspace into dW afterwards
     const int k = k0 + (wk * TK + j) * 32 + l31;
     if (k >= p.K)
       continue;
@@ -284,18 +310,54 @@ __global__ void __launch_bounds__(T) conv_wgrad_f32(const WgradArgs p)
   }
 }
 
+// dW[m][c][t] += ws[m][t][c]; ws is left zeroed for the next layer
+__global__ void wgrad_fold_kernel(float* __restrict__ ws, float* __restrict__ dw, int C, int ss, size_t total)
+{
+  const size_t K = (size_t)C * ss;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+  {
+    const size_t m = i / K, r = i - m * K;      // r = c * ss + t in dW order
+    const int c = (int)(r / ss), t = (int)(r - (size_t)c * ss);
+    const size_t src = m * K + (size_t)t * C + c;
+    dw[i] += ws[src];
+    ws[src] = 0.f;
+  }
+}
+
+// per-device workspace of the tap-major path (stream-ordered use: one suffices), grown on demand, zero on creation
+float* wgrad_workspace(size_t floats, hipStream_t st)
+{
+  static float* buf[64] = {nullptr};
+  static size_t cap[64] = {0};
+  int dev = 0;
+  CHECK_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64)
+    dev = 0;
+  if (cap[dev] < floats)
+  {
+    if (buf[dev])
+    {
+      CHECK_HIP(hipStreamSynchronize(st));
+      CHECK_HIP(hipFree(buf[dev]));
+    }
+    CHECK_HIP(hipMalloc((void**)&buf[dev], floats * sizeof(float)));
+    CHECK_HIP(hipMemsetAsync(buf[dev], 0, floats * sizeof(float), st));
+    cap[dev] = floats;
+  }
+  return buf[dev];
+}
+
 typedef void (*WgradKernel)(const WgradArgs);
 struct WgradCfg
 {
   int tm, tk;
-  WgradKernel kernel[2];  // [AVEC]
+  WgradKernel kernel[4];  // [AVEC + 2 * TMAJ]
 };
-const WgradCfg g_wcfg[] = {
-    {2, 2, {conv_wgrad_f32<2, 2, false>, conv_wgrad_f32<2, 2, true>}},
-    {1, 2, {conv_wgrad_f32<1, 2, false>, conv_wgrad_f32<1, 2, true>}},
-    {2, 1, {conv_wgrad_f32<2, 1, false>, conv_wgrad_f32<2, 1, true>}},
-    {1, 1, {conv_wgrad_f32<1, 1, false>, conv_wgrad_f32<1, 1, true>}},
-};
+#define DK_WG(TMV, TKV)                                                                                     \
+  {TMV, TKV, {conv_wgrad_f32<TMV, TKV, false, false>, conv_wgrad_f32<TMV, TKV, true, false>,               \
+                 conv_wgrad_f32<TMV, TKV, false, true>, conv_wgrad_f32<TMV, TKV, true, true>}}
+const WgradCfg g_wcfg[] = {DK_WG(2, 2), DK_WG(1, 2), DK_WG(2, 1), DK_WG(1, 1)};
+#undef DK_WG
 }  // namespace
 
 extern "C" int dk_conv_backward_weights(const DkConvDesc* d, const float* x, const float* delta,
@@ -324,6 +386,7 @@ extern "C" int dk_conv_backward_weights(const DkConvDesc* d, const float* x, con
     }
   }
   hipStream_t st = stream ? (hipStream_t)stream : get_cuda_stream();
+  float* ws = nullptr;   // tap-major workspace, when that path is taken
   for (int b0 = 0; b0 < d->batch; b0 += chunk)
   {
     const int nb = (d->batch - b0 < chunk) ? d->batch - b0 : chunk;
@@ -346,6 +409,9 @@ extern "C" int dk_conv_backward_weights(const DkConvDesc* d, const float* x, con
       if (force > 0 && force < 4)
         ci |= force;
     }
+    // 3x3 layers with 64 (not 128) channels per tap: 64-tap tiles keep the tap-major path available
+    if (d->size > 1 && (C % 128) != 0 && (C % 64) == 0)
+      ci |= 2;
     const WgradCfg& c = g_wcfg[ci];
     const int BM = 64 * c.tm, BKO = 64 * c.tk;
     a.tiles_m = (M + BM - 1) / BM;
@@ -353,7 +419,9 @@ extern "C" int dk_conv_backward_weights(const DkConvDesc* d, const float* x, con
     a.groups = d->groups;
     const int nstages = (a.N + NC - 1) / NC;
     const long long tiles = (long long)a.tiles_m * a.tiles_k * d->groups;
-    static const long long target = getenv("DK_WGRAD_BLOCKS") ? atoll(getenv("DK_WGRAD_BLOCKS")) : 1024;
+    static const long long target3 = getenv("DK_WGRAD_BLOCKS") ? atoll(getenv("DK_WGRAD_BLOCKS")) : 1024;
+    static const long long target1 = getenv("DK_WGRAD_BLOCKS_1X1") ? atoll(getenv("DK_WGRAD_BLOCKS_1X1")) : 1024;
+    const long long target = d->size == 1 ? target1 : target3;
     long long want = (target + tiles - 1) / tiles;  // ~4 workgroups per CU in total
     if (want < 1) want = 1;
     if (want > nstages) want = nstages;
@@ -363,18 +431,37 @@ extern "C" int dk_conv_backward_weights(const DkConvDesc* d, const float* x, con
     a.nsplit = (nstages + a.stages_per_split - 1) / a.stages_per_split;
     const long long nblk = tiles * a.nsplit;
     const bool avec = (a.OHW % 4 == 0) && (((uintptr_t)a.delta & 15) == 0);
+    // tap-major tiles when a tile never straddles two taps (C a multiple of the tile width) and there is more than one tap
+    static const bool tmaj_on = !(getenv("DK_WGRAD_TMAJ") && !atoi(getenv("DK_WGRAD_TMAJ")));
+    // (a 1x1 layer is its own tap-major order: same fast gather, no workspace)
+    const bool tmaj = tmaj_on && (C % BKO) == 0 && d->pad * d->dilation == (d->size > 1 ? d->pad * d->dilation : 0);
+    const int kv = (avec ? 1 : 0) + (tmaj ? 2 : 0);
+    if (tmaj && d->size > 1)
+    {
+      if (!ws)
+        ws = wgrad_workspace((size_t)d->n * K, st);
+      a.dw = ws;
+    }
     const int lds_bytes = 2 * (BM + BKO) * LS * (int)sizeof(float);
-    dk_set_max_dynamic_lds((const void*)c.kernel[avec], lds_bytes);
+    dk_set_max_dynamic_lds((const void*)c.kernel[kv], lds_bytes);
     DkProfScope prof;
     dk_prof_begin(prof, st);
-    hipLaunchKernelGGL(c.kernel[avec], dim3((unsigned)nblk), dim3(T), lds_bytes, st, a);
+    hipLaunchKernelGGL(c.kernel[kv], dim3((unsigned)nblk), dim3(T), lds_bytes, st, a);
     CHECK_HIP(hipPeekAtLastError());
     if (prof.e0)
     {
       char nm[96];
-      snprintf(nm, sizeof(nm), "conv_wgrad_f32<%d, %d, %s>", c.tm, c.tk, avec ? "true" : "false");
+      snprintf(nm, sizeof(nm), "conv_wgrad_f32<%d, %d, %s, %s>", c.tm, c.tk, avec ? "true" : "false", tmaj ? "true" : "false");
       dk_prof_end(prof, st, dk_prof_named_slot(nm), 2.0 * (double)M * K * d->groups * (double)a.N / 1e9);
     }
+  }
+  if (ws)
+  {
+    const size_t total = (size_t)d->n * K;
+    unsigned gb = (unsigned)((total + 255) / 256);
+    if (gb > 4096u) gb = 4096u;
+    hipLaunchKernelGGL(wgrad_fold_kernel, dim3(gb), dim3(256), 0, st, ws, weight_updates, C, d->size * d->size, total);
+    CHECK_HIP(hipPeekAtLastError());
   }
   return 0;
 }
