@@ -131,7 +131,7 @@ __device__ __forceinline__ void barrier_lds()
 }
 
 template <int VW, bool PAIR>
-__global__ void __launch_bounds__(256) conv3x3_wino_f32(const ConvArgs p)
+__global__ void __launch_bounds__(512) conv3x3_wino_f32(const ConvArgs p)
 {
   constexpr int KMAX = wino_kmax(VW);
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -143,11 +143,18 @@ __global__ void __launch_bounds__(256) conv3x3_wino_f32(const ConvArgs p)
   int g, tile_m, tile_n;
   if (!conv_block_tile(p, g, tile_m, tile_n))
     return;
+  // 8 waves = TWO per SIMD (256 registers each): wave (xh, wn, wm) owns the 32 x 32 sub-block (wm, wn) for the
+  // position rows 2 xh, 2 xh + 1 (8 of the 16 positions, 8 accumulators = 128 AGPRs).  The second wave on a SIMD
+  // hides what one 512-register wave could not: LDS latency, the barrier, the transform slices.  Waves 0-3 also
+  // produce V (input transform), waves 4-7 also issue the LDS-DMA pieces.
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
-  const int wm = wave & 1, wn = wave >> 1;
+  const int xh = wave >> 2, wq = wave & 3;
+  const int wm = wq & 1, wn = wq >> 1;
+  const bool xf_wave = wave < 4, dma_wave = wave >= 4;
+  const int t256 = wq * 64 + lane;             // index inside the 256-thread half this wave belongs to
   const int m0 = tile_m * WBM, n0 = tile_n * WBN;
   const int nst = p.C / WCK;
   const int TW = p.tiles_w, THW = p.tiles_hw, TH = p.wino_th;
@@ -158,8 +165,8 @@ __global__ void __launch_bounds__(256) conv3x3_wino_f32(const ConvArgs p)
   const u32x4_t xr = make_rsrc(p.x, p.x_bytes);
   const u32x4_t ur = make_rsrc(p.w, p.w_bytes);
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)lds);
-  const unsigned u_lds = lds0 + (unsigned)(wave * 64) * 16u;                               // + slot * 16 KB + j * 4 KB
-  const unsigned r_lds = lds0 + (unsigned)((D + 2) * W_STAGE) * 4u + (unsigned)(wave * 64 * VW) * 4u;   // + slot * RAWF * 4 + k * 256 * VW * 4
+  const unsigned u_lds = lds0 + (unsigned)(wq * 64) * 16u;                               // + slot * 16 KB + j * 4 KB
+  const unsigned r_lds = lds0 + (unsigned)((D + 2) * W_STAGE) * 4u + (unsigned)(wq * 64 * VW) * 4u;   // + slot * RAWF * 4 + k * 256 * VW * 4
 
   // ---- geometry of the strip: tile rows R0 .. Rlast (R = b * TH + ty), first tile column tx0 ----
   const int R0 = fdiv(n0, TW, p.inv_tiles_w);
@@ -170,14 +177,14 @@ __global__ void __launch_bounds__(256) conv3x3_wino_f32(const ConvArgs p)
   // first loaded column group of local tile row r: floor((2 * txs - 1) / VW), txs = first tile column staged
   auto g0_of = [&](int r) { const int txs = (wide && r == 0) ? tx0 : 0; return (2 * txs - 1 + VW) / VW - 1; };
 
-  // ---- raw patch pieces: element e = tid + 256 * k is column group g of row (c, r, i) ------------
+  // ---- raw patch pieces (DMA waves): element e = t256 + 256 * k is column group g of row (c, r, i) ---------
   // Padding and ragged edges get an out-of-range source offset: the DMA drops them and the zeros written
   // once below stay (the geometry of a piece does not depend on the stage).
   unsigned xoff[KMAX];
 #pragma unroll
   for (int k = 0; k < KMAX; ++k)
   {
-    const int e = tid + 256 * k;
+    const int e = t256 + 256 * k;
     const int c = fdiv(e, RS * GP, p.inv_wino_rsg);
     const int rem = e - c * RS * GP;
     const int rowi = fdiv(rem, GP, p.inv_wino_gp);
@@ -188,17 +195,17 @@ __global__ void __launch_bounds__(256) conv3x3_wino_f32(const ConvArgs p)
     const int ty = R - b * TH;
     const int iy = 2 * ty - 1 + i;
     const int col0 = VW * (g0_of(r) + gg);
-    const bool ok = k < NK && c < WCK && R <= Rlast && iy >= 0 && iy < p.H && col0 >= 0 && col0 < p.W;
+    const bool ok = dma_wave && k < NK && c < WCK && R <= Rlast && iy >= 0 && iy < p.H && col0 >= 0 && col0 < p.W;
     xoff[k] = ok ? (unsigned)(((b * p.Ctot + c) * p.H + iy) * p.W + col0) * 4u : OOB;
   }
 
-  // ---- input-transform ownership: one (channel, tile) pair per thread -------------------------
+  // ---- input-transform ownership (waves 0-3): one (channel, tile) pair per thread ----------------
   // lane -> channel (lane & 1) + 2 * (lane >> 5), tile (lane >> 1) & 15 of the wave's 16 tiles: the 32
   // lanes of a half-wave write 32 consecutive floats of every position (no bank conflicts).
   const int c4 = (lane & 1) + 2 * lh;
   int rsrc, vdst;
   {
-    const int tl = wave * 16 + ((lane >> 1) & 15);
+    const int tl = wq * 16 + ((lane >> 1) & 15);
     const int n = (n0 + tl < p.N) ? n0 + tl : nlast;
     const int R = fdiv(n, TW, p.inv_tiles_w);
     const int tx = n - R * TW;
@@ -207,19 +214,19 @@ __global__ void __launch_bounds__(256) conv3x3_wino_f32(const ConvArgs p)
     vdst = img_off(0, tl >> 5, tl & 31, c4);
   }
   const unsigned stage_x_bytes = (unsigned)(WCK * p.H * p.W) * 4u;
-  const unsigned ubase = (unsigned)(tile_m * nst) * (unsigned)(W_STAGE * 4) + (unsigned)tid * 16u;
+  const unsigned ubase = (unsigned)(tile_m * nst) * (unsigned)(W_STAGE * 4) + (unsigned)t256 * 16u;
 
-  f32x16 acc[16];
+  f32x16 acc[8];
 #pragma unroll
-  for (int i = 0; i < 16; ++i)
+  for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
   // zero the raw ring once (padding positions are never written again)
-  for (int i = tid; i < D * RAWF; i += 256) Rs[i] = 0.f;
+  for (int i = tid; i < D * RAWF; i += 512) Rs[i] = 0.f;
   barrier_lds();
 
-  // LDS-DMA issue: raw rows of stage s into ring slot s % 3, filters of stage s into ring slot s % 3
+  // LDS-DMA issue (waves 4-7): raw rows of stage s into ring slot s % D, filters of stage s into ring slot s % D
   auto issue_raw = [&](int s) {
     const unsigned xo = (unsigned)s * stage_x_bytes;
     const unsigned dst = r_lds + (unsigned)((s % D) * RAWF) * 4u;
@@ -300,73 +307,123 @@ __global__ void __launch_bounds__(256) conv3x3_wino_f32(const ConvArgs p)
   };
 
   // ---- prologue: raw(0), B(0) .. B(D-2) in flight; V(0) from raw(0) ----------------------------
-  issue_raw(0);
-  issue_bundle(0);
-  issue_bundle(1);
-  if (D > 3)
-    issue_bundle(2);
-  wait_vmcnt_n(bundle_count(0) + bundle_count(1) + (D > 3 ? bundle_count(2) : 0));
+  if (dma_wave)
+  {
+    issue_raw(0);
+    issue_bundle(0);
+    issue_bundle(1);
+    if (D > 3)
+      issue_bundle(2);
+    wait_vmcnt_n(bundle_count(0) + bundle_count(1) + (D > 3 ? bundle_count(2) : 0));
+  }
   barrier_lds();
-  tslice(std::integral_constant<int, 0>(), Rs, Vs);
-  tslice(std::integral_constant<int, 1>(), Rs, Vs);
-  tslice(std::integral_constant<int, 2>(), Rs, Vs);
-  tslice(std::integral_constant<int, 3>(), Rs, Vs);
-  tslice(std::integral_constant<int, 4>(), Rs, Vs);
-  tslice(std::integral_constant<int, 5>(), Rs, Vs);
-  tslice(std::integral_constant<int, 6>(), Rs, Vs);
-  tslice(std::integral_constant<int, 7>(), Rs, Vs);
+  if (xf_wave)
+  {
+    tslice(std::integral_constant<int, 0>(), Rs, Vs);
+    tslice(std::integral_constant<int, 1>(), Rs, Vs);
+    tslice(std::integral_constant<int, 2>(), Rs, Vs);
+    tslice(std::integral_constant<int, 3>(), Rs, Vs);
+    tslice(std::integral_constant<int, 4>(), Rs, Vs);
+    tslice(std::integral_constant<int, 5>(), Rs, Vs);
+    tslice(std::integral_constant<int, 6>(), Rs, Vs);
+    tslice(std::integral_constant<int, 7>(), Rs, Vs);
+  }
 
   for (int t = 0; t < nst; ++t)
   {
-    // B(t) has landed for this wave; behind the barrier for every wave, and every wave has left
+    // B(t) has landed for the issuing wave; behind the barrier for every wave, and every wave has left
     // iteration t - 1 (V(t) complete; ring slots of U(t-1) and raw(t) free)
-    if (!(DK_WABL & 8))
+    if (dma_wave && !(DK_WABL & 8))
       wait_vmcnt_n(bundle_count(t + 1) + (D > 3 ? bundle_count(t + 2) : 0));
     barrier_lds();
-    issue_bundle(t + D - 1);
-    const float2* const Ua = (const float2*)(Us + (t % D) * W_STAGE) + wm * 64 + lh * 32 + l31;
-    const float2* const Va = (const float2*)(Vs + (t & 1) * W_STAGE) + wn * 64 + lh * 32 + l31;
+    if (dma_wave)
+      issue_bundle(t + D - 1);
+    const float2* const Ua = (const float2*)(Us + (t % D) * W_STAGE) + (xh * 8) * 128 + wm * 64 + lh * 32 + l31;
+    const float2* const Va = (const float2*)(Vs + (t & 1) * W_STAGE) + (xh * 8) * 128 + wn * 64 + lh * 32 + l31;
     const float* const Rcur = Rs + ((t + 1) % D) * RAWF;
     float* const Vnext = Vs + ((t + 1) & 1) * W_STAGE;
-    // ---- 16 positions x 2 k-pairs, four positions at a time with their MFMAs interleaved; the
-    // fragments of the next group are requested before the MFMAs of the current one are issued,
-    // and behind each MFMA round sits one slice of the NEXT stage's input transform (after the
-    // last stage it works on stale rows into the unused V half: harmless).
+    // ---- this wave's 8 positions x 2 k-pairs, four positions at a time with their MFMAs interleaved; the
+    // fragments of the second group are requested before the MFMAs of the first are issued; behind each MFMA
+    // round the transform waves place two slices of the NEXT stage's input transform (after the last stage
+    // they work on stale rows into the unused V half: harmless).
     float2 fa[2][4], fb[2][4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-    {
-      fa[0][u] = Ua[u * 128];
-      fb[0][u] = Va[u * 128];
-    }
+    for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+      {
+        fa[gq][u] = Ua[(gq * 4 + u) * 128];
+        fb[gq][u] = Va[(gq * 4 + u) * 128];
+      }
     auto group = [&](auto gc) {
       constexpr int grp = decltype(gc)::value;
-      if constexpr (grp + 1 < 4)
-      {
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-        {
-          fa[(grp + 1) & 1][u] = Ua[((grp + 1) * 4 + u) * 128];
-          fb[(grp + 1) & 1][u] = Va[((grp + 1) * 4 + u) * 128];
-        }
+      for (int u = 0; u < 4; ++u) acc[grp * 4 + u] = mfma2(fa[grp][u].x, fb[grp][u].x, acc[grp * 4 + u]);
+      if (xf_wave)
+      {
+        tslice(std::integral_constant<int, grp * 4 + 0>(), Rcur, Vnext);
+        tslice(std::integral_constant<int, grp * 4 + 1>(), Rcur, Vnext);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc[grp * 4 + u] = mfma2(fa[grp & 1][u].x, fb[grp & 1][u].x, acc[grp * 4 + u]);
-      tslice(std::integral_constant<int, grp * 2 + 0>(), Rcur, Vnext);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) acc[grp * 4 + u] = mfma2(fa[grp & 1][u].y, fb[grp & 1][u].y, acc[grp * 4 + u]);
-      tslice(std::integral_constant<int, grp * 2 + 1>(), Rcur, Vnext);
+      for (int u = 0; u < 4; ++u) acc[grp * 4 + u] = mfma2(fa[grp][u].y, fb[grp][u].y, acc[grp * 4 + u]);
+      if (xf_wave)
+      {
+        tslice(std::integral_constant<int, grp * 4 + 2>(), Rcur, Vnext);
+        tslice(std::integral_constant<int, grp * 4 + 3>(), Rcur, Vnext);
+      }
       __builtin_amdgcn_sched_barrier(0);
     };
     group(std::integral_constant<int, 0>());
     group(std::integral_constant<int, 1>());
-    group(std::integral_constant<int, 2>());
-    group(std::integral_constant<int, 3>());
   }
 
-  // ---- output transform A^T Mx A, bias, activation (+ residual), store ----------------------
+  // ---- output transform A^T Mx A across the two waves that share a sub-block ------------------------
+  // Rows 2 xh, 2 xh + 1 of the 4x4 position grid are in this wave: t_q[i] = row sums (q = 0: M0 + M1 + M2,
+  // q = 1: M1 - M2 - M3).  Y0q = (t_q[0] + t_q[1]) + t_q[2], Y1q = (t_q[1] - t_q[2]) - t_q[3]: wave xh = 0 holds the
+  // bracketed parts, wave xh = 1 holds t_q[2], t_q[3].  Each wave finishes HALF of the 16 C/D registers (xh = 0:
+  // r < 8, xh = 1: r >= 8) and hands the partner, through LDS, the four partial values per register of the other half.
+  barrier_lds();   // every MFMA operand read is done: the rings' LDS is free
+  float* const Ex = lds;   // [8 waves][8 registers][4 values][64 lanes]
+  float part[16][4];
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+  {
+    float t0[2], t1[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+    {
+      t0[i] = acc[i * 4 + 0][r] + acc[i * 4 + 1][r] + acc[i * 4 + 2][r];
+      t1[i] = acc[i * 4 + 1][r] - acc[i * 4 + 2][r] - acc[i * 4 + 3][r];
+    }
+    if (xh == 0)
+    {
+      part[r][0] = t0[0] + t0[1];   // Y00 without t0[2]
+      part[r][1] = t1[0] + t1[1];   // Y01 without t1[2]
+      part[r][2] = t0[1];           // Y10 before - t0[2] - t0[3]
+      part[r][3] = t1[1];           // Y11 before - t1[2] - t1[3]
+    }
+    else
+    {
+      part[r][0] = t0[0];           // t0[2] of the 4x4 grid
+      part[r][1] = t1[0];           // t1[2]
+      part[r][2] = t0[1];           // t0[3]
+      part[r][3] = t1[1];           // t1[3]
+    }
+  }
+  {
+    float* const mine = Ex + (size_t)(wave * 8) * 4 * 64 + lane;
+    const int rbase = xh == 0 ? 8 : 0;   // the half the PARTNER finishes
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) mine[(rr * 4 + k) * 64] = xh == 0 ? part[8 + rr][k] : part[rr][k];
+    (void)rbase;
+  }
+  barrier_lds();
+  const float* const theirs = Ex + (size_t)((wave ^ 4) * 8) * 4 * 64 + lane;
+
   const int n = n0 + wn * 32 + l31;
   const bool nv = n < p.N;
   const int nn = nv ? n : 0;
@@ -389,26 +446,34 @@ __global__ void __launch_bounds__(256) conv3x3_wino_f32(const ConvArgs p)
   // the activation is a launch constant: dispatched once into straight-line code
   auto emit = [&](auto actc) {
     constexpr int A = decltype(actc)::value;
-  #pragma unroll
-    for (int r = 0; r < 16; ++r)
+#pragma unroll
+    for (int rr8 = 0; rr8 < 8; ++rr8)
     {
+      const int r = xh * 8 + rr8;     // xh is wave-uniform: both halves are compiled, one runs
+      float q[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) q[k] = theirs[(rr8 * 4 + k) * 64];
+      float y00, y01, y10, y11;
+      if (xh == 0)
+      {
+        y00 = part[rr8][0] + q[0];
+        y01 = part[rr8][1] + q[1];
+        y10 = part[rr8][2] - q[0] - q[2];
+        y11 = part[rr8][3] - q[1] - q[3];
+      }
+      else
+      {
+        y00 = q[0] + part[8 + rr8][0];
+        y01 = q[1] + part[8 + rr8][1];
+        y10 = q[2] - part[8 + rr8][0] - part[8 + rr8][2];
+        y11 = q[3] - part[8 + rr8][1] - part[8 + rr8][3];
+      }
       const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       const float bv = p.bias ? p.bias[m] : 0.f;
-      float t0[4], t1[4];
-  #pragma unroll
-      for (int i = 0; i < 4; ++i)
-      {
-        t0[i] = acc[i * 4 + 0][r] + acc[i * 4 + 1][r] + acc[i * 4 + 2][r];
-        t1[i] = acc[i * 4 + 1][r] - acc[i * 4 + 2][r] - acc[i * 4 + 3][r];
-      }
-      float y00 = t0[0] + t0[1] + t0[2] + bv;
-      float y01 = t1[0] + t1[1] + t1[2] + bv;
-      float y10 = t0[1] - t0[2] - t0[3] + bv;
-      float y11 = t1[1] - t1[2] - t1[3] + bv;
-      y00 = dk_activate(y00, A < 0 ? act : A);
-      y01 = dk_activate(y01, A < 0 ? act : A);
-      y10 = dk_activate(y10, A < 0 ? act : A);
-      y11 = dk_activate(y11, A < 0 ? act : A);
+      y00 = dk_activate(y00 + bv, A < 0 ? act : A);
+      y01 = dk_activate(y01 + bv, A < 0 ? act : A);
+      y10 = dk_activate(y10 + bv, A < 0 ? act : A);
+      y11 = dk_activate(y11 + bv, A < 0 ? act : A);
       const unsigned mo = (unsigned)m * row_bytes;
       if (PAIR)
       {
@@ -622,7 +687,7 @@ int dk_conv_wino_launch(ConvArgs a, int c, hipStream_t st)
   const int bytes = ((a.wino_ring + 2) * W_STAGE + a.wino_ring * raw_f) * (int)sizeof(float);
   void (*k)(const ConvArgs) = o.vw == 4 ? conv3x3_wino_f32<4, true> : (pair ? conv3x3_wino_f32<1, true> : conv3x3_wino_f32<1, false>);
   dk_set_max_dynamic_lds((const void*)k, bytes);
-  hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), bytes, st, a);
+  hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(512), bytes, st, a);
   return o.vw == 4 ? 0 : (pair ? 1 : 2);
 }
 
