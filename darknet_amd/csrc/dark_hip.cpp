@@ -166,7 +166,9 @@ DK_EXPORT float* cuda_make_array(float* x, size_t n)
 {
   float* x_gpu = nullptr;
   size_t size = sizeof(float) * n;
-  hipError_t status = hipMalloc((void**)&x_gpu, size ? size : 4);
+  // 64 bytes of slack behind every device array: kernels that fetch 16-byte pieces of rows whose length is not a
+  // multiple of 4 floats (conv3x3_wino.hip) may read up to 12 bytes past the last element (the values are masked)
+  hipError_t status = hipMalloc((void**)&x_gpu, (size ? size : 4) + 64);
   if (status != hipSuccess)
     fprintf(stderr, " Try to set subdivisions=64 in your cfg-file. \n");  // dark_cuda.c:432-435
   CHECK_HIP(status);

@@ -53,6 +53,12 @@
 #ifndef DK_WABL
 #define DK_WABL 0
 #endif
+// scheduling fences around the MFMA rounds (bit 4 of DK_WABL compiles them out: measurement of their worth)
+#if DK_WABL & 16
+#define DK_WINO_SB
+#else
+#define DK_WINO_SB __builtin_amdgcn_sched_barrier(0)
+#endif
 
 namespace
 {
@@ -162,7 +168,10 @@ __global__ void __launch_bounds__(512) conv3x3_wino_f32(const ConvArgs p)
   const int Pw = VW * GP;
   const int RAWF = NK * 256 * VW;
 
-  const u32x4_t xr = make_rsrc(p.x, p.x_bytes);
+  // 16-byte pieces may straddle the end of a row whose length is not a multiple of 4 floats: the last piece of the
+  // tensor then reads up to 12 bytes past it (masked in the transform; device arrays carry 64 bytes of slack,
+  // dark_hip.cpp: cuda_make_array) -- the descriptor must not drop that piece as out of range
+  const u32x4_t xr = make_rsrc(p.x, p.x_bytes + (VW == 4 ? 16u : 0u));
   const u32x4_t ur = make_rsrc(p.w, p.w_bytes);
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)lds);
   const unsigned u_lds = lds0 + (unsigned)(wq * 64) * 16u;                               // + slot * 16 KB + j * 4 KB
@@ -195,7 +204,8 @@ __global__ void __launch_bounds__(512) conv3x3_wino_f32(const ConvArgs p)
     const int ty = R - b * TH;
     const int iy = 2 * ty - 1 + i;
     const int col0 = VW * (g0_of(r) + gg);
-    const bool ok = dma_wave && k < NK && c < WCK && R <= Rlast && iy >= 0 && iy < p.H && col0 >= 0 && col0 < p.W;
+    // a piece is fetched when it INTERSECTS its row (its columns outside the row are masked by the transform)
+    const bool ok = dma_wave && k < NK && c < WCK && R <= Rlast && iy >= 0 && iy < p.H && col0 > -VW && col0 < p.W;
     xoff[k] = ok ? (unsigned)(((b * p.Ctot + c) * p.H + iy) * p.W + col0) * 4u : OOB;
   }
 
@@ -204,12 +214,17 @@ __global__ void __launch_bounds__(512) conv3x3_wino_f32(const ConvArgs p)
   // lanes of a half-wave write 32 consecutive floats of every position (no bank conflicts).
   const int c4 = (lane & 1) + 2 * lh;
   int rsrc, vdst;
+  unsigned cmask = 0;   // bit j: patch column 2 tx - 1 + j lies outside the row (left / right padding)
   {
     const int tl = wq * 16 + ((lane >> 1) & 15);
     const int n = (n0 + tl < p.N) ? n0 + tl : nlast;
     const int R = fdiv(n, TW, p.inv_tiles_w);
     const int tx = n - R * TW;
     const int r = R - R0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if ((unsigned)(2 * tx - 1 + j) >= (unsigned)p.W)
+        cmask |= 1u << j;
     rsrc = (c4 * RS + 4 * r) * Pw + 2 * tx - 1 - VW * g0_of(r);
     vdst = img_off(0, tl >> 5, tl & 31, c4);
   }
@@ -274,7 +289,11 @@ __global__ void __launch_bounds__(512) conv3x3_wino_f32(const ConvArgs p)
         const float d0 = src[0];
         const float2 mid = *(const float2*)(src + 1);
         const float d3 = src[3];
-        dd[part][0] = d0; dd[part][1] = mid.x; dd[part][2] = mid.y; dd[part][3] = d3;
+        // columns outside the row hold whatever the straddling piece brought along: they are padding
+        dd[part][0] = (cmask & 1u) ? 0.f : d0;
+        dd[part][1] = (cmask & 2u) ? 0.f : mid.x;
+        dd[part][2] = (cmask & 4u) ? 0.f : mid.y;
+        dd[part][3] = (cmask & 8u) ? 0.f : d3;
       }
       else
       {
@@ -357,7 +376,7 @@ __global__ void __launch_bounds__(512) conv3x3_wino_f32(const ConvArgs p)
       }
     auto group = [&](auto gc) {
       constexpr int grp = decltype(gc)::value;
-      __builtin_amdgcn_sched_barrier(0);
+      DK_WINO_SB;
 #pragma unroll
       for (int u = 0; u < 4; ++u) acc[grp * 4 + u] = mfma2(fa[grp][u].x, fb[grp][u].x, acc[grp * 4 + u]);
       if (xf_wave)
@@ -365,7 +384,7 @@ __global__ void __launch_bounds__(512) conv3x3_wino_f32(const ConvArgs p)
         tslice(std::integral_constant<int, grp * 4 + 0>(), Rcur, Vnext);
         tslice(std::integral_constant<int, grp * 4 + 1>(), Rcur, Vnext);
       }
-      __builtin_amdgcn_sched_barrier(0);
+      DK_WINO_SB;
 #pragma unroll
       for (int u = 0; u < 4; ++u) acc[grp * 4 + u] = mfma2(fa[grp][u].y, fb[grp][u].y, acc[grp * 4 + u]);
       if (xf_wave)
@@ -373,7 +392,7 @@ __global__ void __launch_bounds__(512) conv3x3_wino_f32(const ConvArgs p)
         tslice(std::integral_constant<int, grp * 4 + 2>(), Rcur, Vnext);
         tslice(std::integral_constant<int, grp * 4 + 3>(), Rcur, Vnext);
       }
-      __builtin_amdgcn_sched_barrier(0);
+      DK_WINO_SB;
     };
     group(std::integral_constant<int, 0>());
     group(std::integral_constant<int, 1>());
@@ -612,10 +631,12 @@ bool wino_geometry(int TW, int vw, WinoGeo& o)
   return false;
 }
 
-// 16-byte pieces when the rows are 16-byte aligned (W % 4 == 0), else 4-byte pieces
-bool wino_pick(int W, int TW, bool aligned16, WinoGeo& o)
+// 16-byte pieces whenever their geometry fits (rows of any length: a piece may straddle a row end, the transform
+// masks the columns outside the row), else 4-byte pieces
+bool wino_pick(int W, int TW, bool allow16, WinoGeo& o)
 {
-  if (W % 4 == 0 && aligned16 && wino_geometry(TW, 4, o))
+  (void)W;
+  if (allow16 && wino_geometry(TW, 4, o))
     return true;
   return wino_geometry(TW, 1, o);
 }
@@ -624,8 +645,9 @@ int dk_conv_wino_num_configs() { return 1; }
 const char* dk_conv_wino_config_name(int c) { return c == 0 ? "wino_64x64" : nullptr; }
 const char* dk_conv_wino_kernel_name(int c, int variant)
 {
-  static const char* names[3] = {"conv3x3_wino_f32<4, true>", "conv3x3_wino_f32<1, true>", "conv3x3_wino_f32<1, false>"};
-  return (c == 0 && variant >= 0 && variant < 3) ? names[variant] : nullptr;
+  static const char* names[4] = {"conv3x3_wino_f32<4, true>", "conv3x3_wino_f32<4, false>", "conv3x3_wino_f32<1, true>",
+      "conv3x3_wino_f32<1, false>"};
+  return (c == 0 && variant >= 0 && variant < 4) ? names[variant] : nullptr;
 }
 bool dk_conv_wino_applicable(const DkConvDesc* d, int c)
 {
@@ -641,8 +663,8 @@ const float* dk_conv_wino_lookup(const float* weights)
 }
 
 // Launches one batch chunk; a.w must already point at the transformed filters.  Returns the variant
-// (0: 16-byte row pieces, 1: 4-byte pieces / paired stores, 2: 4-byte pieces / single stores), or -1 when the
-// geometry does not fit (caller falls back).
+// (0 / 1: 16-byte row pieces with paired / single stores, 2 / 3: 4-byte pieces), or -1 when the geometry does not fit
+// (caller falls back).
 int dk_conv_wino_launch(ConvArgs a, int c, hipStream_t st)
 {
   (void)c;
@@ -650,8 +672,8 @@ int dk_conv_wino_launch(ConvArgs a, int c, hipStream_t st)
   const int nb = a.N / a.OHW;
   const bool pair = (a.OW % 2 == 0) && (((uintptr_t)a.y & 7) == 0) && (!a.residual || ((uintptr_t)a.residual & 7) == 0);
   WinoGeo o;
-  const bool a16 = pair && ((uintptr_t)a.x & 15) == 0;
-  if (!wino_pick(a.W, TW, a16, o))
+  static const bool allow16 = !(getenv("DK_WINO_VW1") && atoi(getenv("DK_WINO_VW1")));   // diagnostics: force 4-byte pieces
+  if (!wino_pick(a.W, TW, allow16 && ((uintptr_t)a.x & 3) == 0, o))
     return -1;
   a.tiles_w = TW;
   a.tiles_hw = TH * TW;
@@ -685,10 +707,11 @@ int dk_conv_wino_launch(ConvArgs a, int c, hipStream_t st)
       a.wino_ring = 4;
   }
   const int bytes = ((a.wino_ring + 2) * W_STAGE + a.wino_ring * raw_f) * (int)sizeof(float);
-  void (*k)(const ConvArgs) = o.vw == 4 ? conv3x3_wino_f32<4, true> : (pair ? conv3x3_wino_f32<1, true> : conv3x3_wino_f32<1, false>);
+  void (*k)(const ConvArgs) = o.vw == 4 ? (pair ? conv3x3_wino_f32<4, true> : conv3x3_wino_f32<4, false>)
+                                        : (pair ? conv3x3_wino_f32<1, true> : conv3x3_wino_f32<1, false>);
   dk_set_max_dynamic_lds((const void*)k, bytes);
   hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(512), bytes, st, a);
-  return o.vw == 4 ? 0 : (pair ? 1 : 2);
+  return (o.vw == 4 ? 0 : 2) + (pair ? 0 : 1);
 }
 
 extern "C" size_t dk_conv_wino_weights_size(const DkConvDesc* d)

@@ -976,9 +976,12 @@ int dk_conv_forward_cfg(const DkConvDesc* d, const float* x, const float* weight
       aw.w = wino_u;
       const int variant = dk_conv_wino_launch(aw, want - wino_base(), st);
       CHECK_HIP(hipPeekAtLastError());
-      dk_prof_end(ps, st, want * 4 + (variant < 0 ? 3 : variant), variant < 0 ? 0.0 : 2.0 * (double)M * K * (double)a.N / 1e9);
       if (variant >= 0)
+      {
+        dk_prof_end(ps, st, want * 4 + variant, 2.0 * (double)M * K * (double)a.N / 1e9);
         continue;
+      }
+      dk_prof_end(ps, st, dk_prof_named_slot("conv3x3_wino_f32 (geometry does not fit: fell back)"), 0.0);
       want = -1;   // raw-patch geometry does not fit the compiled load counts: take the direct kernel
     }
     if (want < 0)

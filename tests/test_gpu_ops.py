@@ -381,6 +381,5 @@ def test_conv_winograd_vs_oracle(gpu, case):
     L.dk_profile_read(out, 256)
     L.dk_profile_enable(0)
     for cfg in wino:
-        # variants 0-2 = 16 / 8 / 4-byte row loads; slot 3 books a launch that fell back to the direct kernel
-        assert sum(out[(cfg * 4 + v) * 3] for v in range(3)) == 1 and out[(cfg * 4 + 3) * 3] == 0, \
-            "config %s did not launch" % names[cfg]
+        # variants: 16- or 4-byte row pieces x paired or single stores; a launch that fell back books none of them
+        assert sum(out[(cfg * 4 + v) * 3] for v in range(4)) == 1, "config %s did not launch" % names[cfg]
