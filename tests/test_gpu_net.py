@@ -466,3 +466,23 @@ def test_device_nms_vs_reference_golden(gpu, weights, name):
     assert np.allclose(mass, g["nms_kept_prob_sum"][orf], rtol=2e-5, atol=1e-7)
     assert keep.sum() < (g["nms_kept_per_det"] >= 0).size * classes   # something was suppressed
     net.close()
+
+
+def test_bench_two_ranks_rehearsal(gpu):
+    """`python bench.py --gpus 2` end to end on ONE GPU (DK_BENCH_REHEARSE: gloo instead of RCCL, both ranks on
+    device 0): the self-launcher (fresh child processes through torch.distributed.run on 127.0.0.1), the shard of the
+    global batch per rank, the barrier-bracketed timing and the rank-0 JSON line with the whole-job rate.  The real
+    N > 1 runs (RCCL, one GPU per rank) are the driver's."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DK_BENCH_REHEARSE="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--cfg", "yolov4-tiny", "--batch", "4"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=400)
+    assert r.returncode == 0, r.stderr.decode()[-600:]
+    line = [l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 8 and d["value"] > 0 and d["unit"] == "images/sec"
