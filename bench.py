@@ -16,11 +16,16 @@ PCIe-inclusive rate (H2D input + D2H heads) is reported beside it as
 disjoint image shards (no data-path collective): scaling = weak.
 
 The JSON line also carries
-  roofline      -- the dominant conv kernel (one tile configuration of
-                   conv_igemm_f32): algorithmic FLOPs per launch (the reference's
-                   counter 2*nweights*oh*ow*batch, src/convolutional_layer.cpp:714)
+  roofline      -- the dominant conv kernel (the instantiation with the largest share of
+                   the step): ALGORITHMIC FLOPs per launch (the reference's counter
+                   2*nweights*oh*ow*batch, src/convolutional_layer.cpp:714 = SURVEY 8d)
                    / its average launch duration from HIP events on the kernel's
-                   own stream, against the 157.3 TFLOP/s dense fp32 MFMA peak.
+                   own stream, against the 157.3 TFLOP/s dense fp32 MFMA peak.  A launch
+                   of the Winograd kernel is booked with the DIRECT algorithm's count;
+                   `mfma_executed_tflops` says what the MFMA pipe really executed (2.25x
+                   fewer).  `traffic` = HBM bytes per launch of that kernel from the
+                   committed rocprofv3 --pmc summary of this workload
+                   (profiles/round*_c{2,3,5}/traffic_summary.json).
   cpu_baseline  -- the reference's CPU path (oracle/_ref/libref_fast.so when it
                    travelled with the repo, else this repo's oracle port) timed
                    on this box's host cores on yolov4 608x608 b=1.
