@@ -1222,6 +1222,7 @@ void FreeNetwork(Network* net)
       cuda_free_host(net->input_pinned_cpu);
     cuda_free(net->workspace);
     cuda_free(net->wt_scratch_gpu);
+    cuda_free(net->wino_scratch_gpu);
     cuda_free(net->delta_arena_gpu);
     cuda_free(net->cand_gpu);
     cuda_free((float*)net->cand_counter_gpu);

@@ -580,6 +580,16 @@ static bool parse_cfg_batch(Network* net, char const* filename, bool train, int 
         if (net->layers[i].type == CONVOLUTIONAL && (size_t)net->layers[i].nweights > maxw)
           maxw = net->layers[i].nweights;
       net->wt_scratch_gpu = cuda_make_array(0, maxw);
+      // Winograd filters of one 3x3 layer (16 values per (filter, channel) pair instead of 9)
+      size_t maxu = 0;
+      for (int i = 0; i < net->n; ++i)
+      {
+        const layer* l = &net->layers[i];
+        if (l->type == CONVOLUTIONAL && l->size == 3 && (size_t)16 * l->n * (l->c / l->groups) > maxu)
+          maxu = (size_t)16 * l->n * (l->c / l->groups);
+      }
+      if (maxu)
+        net->wino_scratch_gpu = cuda_make_array(0, maxu);
       DkBuildDeltaArena(net);
     }
     // tap tables of every conv shape exist before anybody can capture a stream (train and

@@ -87,6 +87,7 @@ void ResizeNetwork(Network* net, int w, int h)
     l->out_view_ctot = 0;
     l->out_alias = nullptr;
     l->conv_cfg = -1;
+    l->train_plan[0] = l->train_plan[1] = l->train_plan[2] = 0;
     switch (l->type)
     {
       case CONVOLUTIONAL:

@@ -11,6 +11,8 @@
 // sum of delta (the CPU reference leaves it 0 -- quirk 3).
 #include <chrono>
 #include <future>
+#include <map>
+#include <mutex>
 #include <stdio.h>
 #include <vector>
 #include <stdlib.h>
@@ -33,6 +35,156 @@ static DkConvDesc conv_desc_of(const layer* l, int activation)
   return d;
 }
 
+// ---- first-step kernel selection for the three GEMMs of a training step ----------------------
+// The inference plan times every tile configuration per layer at load (network.cpp); a train-mode
+// network does the same lazily, on the layer's OWN tensors the first time the layer runs: forward
+// (raw convolution), data gradient, weight gradient.  Results are kept per (device, shape) for the
+// whole process -- replicas of one model must run the same kernels, or their sums stop being bitwise
+// comparable -- and the choice per layer (l->train_plan[k] = configuration + 2).  DK_AUTOTUNE=0 / DkSetAutotune(0) or
+// DK_TRAIN_TUNE=0 keep the heuristics; DK_TRAIN_WINO=0 keeps the Winograd kernel out of training.
+namespace
+{
+struct TrainTune
+{
+  std::mutex mu;
+  std::map<std::vector<int>, int> best;
+  double seconds = 0;
+};
+TrainTune g_tune;
+
+bool train_tune_on()
+{
+  static const int env = getenv("DK_TRAIN_TUNE") ? atoi(getenv("DK_TRAIN_TUNE")) : -1;
+  if (env >= 0)
+    return env != 0;
+  const char* e = getenv("DK_AUTOTUNE");
+  return e ? atoi(e) != 0 : g_dk_autotune != 0;
+}
+bool train_wino_on()
+{
+  static const int env = getenv("DK_TRAIN_WINO") ? atoi(getenv("DK_TRAIN_WINO")) : 1;
+  return env != 0;
+}
+
+std::vector<int> tune_key(int kind, const DkConvDesc& d)
+{
+  return {cuda_get_device(), kind, d.batch, d.c, d.h, d.w, d.n, d.groups, d.size, d.stride_x, d.stride_y, d.dilation,
+      d.pad};
+}
+
+// times launch(cfg) for every candidate (minimum of three timings of two launches, as the inference
+// tuner) and returns the fastest; `heur` wins when it is within 3 % of the fastest (timing noise)
+template <class Launch>
+int time_candidates(const std::vector<int>& cands, int heur, Launch launch, hipStream_t st)
+{
+  hipEvent_t e0, e1;
+  CHECK_HIP(hipEventCreate(&e0));
+  CHECK_HIP(hipEventCreate(&e1));
+  int best = heur;
+  float best_ms = 1e30f, heur_ms = -1.f;
+  for (int c : cands)
+  {
+    launch(c);
+    float ms = 1e30f;
+    for (int rep = 0; rep < 3; ++rep)
+    {
+      CHECK_HIP(hipEventRecord(e0, st));
+      launch(c);
+      launch(c);
+      CHECK_HIP(hipEventRecord(e1, st));
+      CHECK_HIP(hipEventSynchronize(e1));
+      float t = 0;
+      CHECK_HIP(hipEventElapsedTime(&t, e0, e1));
+      if (t < ms)
+        ms = t;
+    }
+    if (c == heur)
+      heur_ms = ms;
+    if (ms < best_ms)
+    {
+      best_ms = ms;
+      best = c;
+    }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (heur_ms > 0 && best != heur && heur_ms <= best_ms * 1.03f)
+    best = heur;
+  return best;
+}
+
+// the choice for (kind, shape): cached, else timed now through `launch`
+template <class Launch>
+int train_choice(layer* l, int kind, const DkConvDesc& d, const std::vector<int>& cands, int heur,
+    Launch launch, hipStream_t st)
+{
+  if (l->train_plan[kind])
+    return l->train_plan[kind] - 2;
+  int choice = heur;
+  if (train_tune_on() && cands.size() > 1)
+  {
+    const std::vector<int> key = tune_key(kind, d);
+    bool known = false;
+    {
+      std::lock_guard<std::mutex> lk(g_tune.mu);
+      auto it = g_tune.best.find(key);
+      if (it != g_tune.best.end())
+      {
+        choice = it->second;
+        known = true;
+      }
+    }
+    if (!known)
+    {
+      const auto t0 = std::chrono::steady_clock::now();
+      choice = time_candidates(cands, heur, launch, st);
+      std::lock_guard<std::mutex> lk(g_tune.mu);
+      g_tune.best[key] = choice;
+      g_tune.seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+  }
+  l->train_plan[kind] = choice + 2;
+  return choice;
+}
+
+// every forward configuration that can run convolution `d` (Winograd only with a filter scratch)
+std::vector<int> forward_candidates(const DkConvDesc& d, bool wino_ok)
+{
+  std::vector<int> v;
+  const int n = dk_conv_num_configs();
+  for (int c = 0; c < n; ++c)
+    if (dk_conv_config_applicable(&d, c) && (!dk_conv_config_is_wino(c) || wino_ok))
+      v.push_back(c);
+  return v;
+}
+
+// raw convolution y = w * x through configuration cfg; Winograd takes freshly transformed filters
+// from the network's scratch (stream-ordered: one scratch serves every layer)
+void train_conv(Network* net, const DkConvDesc& d, const float* x, const float* w, float* y, int cfg, hipStream_t st,
+    const char* what)
+{
+  const float* u = nullptr;
+  if (cfg >= 0 && dk_conv_config_is_wino(cfg))
+  {
+    if (dk_conv_wino_transform_weights(&d, w, net->wino_scratch_gpu, st))
+      error(what);
+    u = net->wino_scratch_gpu;
+  }
+  if (dk_conv_forward_cfg(&d, x, w, nullptr, y, nullptr, nullptr, st, cfg, 0, nullptr, u))
+    error(what);
+}
+}  // namespace
+
+extern "C" LIB_API double DkTrainTuneSeconds()
+{
+  std::lock_guard<std::mutex> lk(g_tune.mu);
+  return g_tune.seconds;
+}
+extern "C" LIB_API int DkLayerTrainCfg(Network* net, int i, int kind)
+{
+  return (i >= 0 && i < net->n && kind >= 0 && kind < 3) ? net->layers[i].train_plan[kind] - 2 : -3;
+}
+
 // conv with un-folded batch norm: raw GEMM -> x_gpu, statistics, normalise+scale+bias+act
 void ForwardConvTrainGpu(layer* l, NetworkState state)
 {
@@ -48,10 +200,20 @@ void ForwardConvTrainGpu(layer* l, NetworkState state)
     temp = true;
   }
   DkConvDesc d = conv_desc_of(l, (int)LINEAR);
-  if (dk_conv_forward_cfg(&d, state.input, l->weights_gpu, nullptr, raw, nullptr, nullptr, st, -1))
+  const int train = state.train && !temp;
+  int cfg = -1;
+  if (train)
+  {
+    Network* net = state.net;
+    const bool wino_ok = train_wino_on() && net->wino_scratch_gpu != nullptr;
+    const float* x = state.input;
+    cfg = train_choice(l, 0, d, forward_candidates(d, wino_ok), dk_conv_pick_config(&d),
+        [&](int c) { train_conv(net, d, x, l->weights_gpu, raw, c, st, "ForwardConvolutionalLayerGpu (train, timing) failed"); }, st);
+    train_conv(net, d, x, l->weights_gpu, raw, cfg, st, "ForwardConvolutionalLayerGpu (train) failed");
+  }
+  else if (dk_conv_forward_cfg(&d, state.input, l->weights_gpu, nullptr, raw, nullptr, nullptr, st, -1))
     error("ForwardConvolutionalLayerGpu (train) failed");
   // x_norm / pre-activation are not stored: the fused backward recomputes them from x
-  const int train = state.train && !temp;
   if (dk_bn_forward_train(raw, nullptr, nullptr, nullptr, l->output_gpu, l->mean_gpu,
           l->variance_gpu, l->rolling_mean_gpu, l->rolling_variance_gpu, l->scales_gpu,
           l->biases_gpu, l->batch, l->n, spatial, (int)l->activation, train, st))
@@ -62,6 +224,7 @@ void ForwardConvTrainGpu(layer* l, NetworkState state)
 void BackwardConvolutionalLayerGpu(layer* l, NetworkState state)
 {
   hipStream_t st = get_cuda_stream();
+  Network* net = state.net;
   const int spatial = l->out_h * l->out_w;
   const size_t total = (size_t)l->batch * l->outputs;
   if (l->batch_normalize)
@@ -80,29 +243,54 @@ void BackwardConvolutionalLayerGpu(layer* l, NetworkState state)
   }
 
   DkConvDesc d = conv_desc_of(l, (int)LINEAR);
-  if (dk_conv_backward_weights(&d, state.input, l->delta_gpu, l->weight_updates_gpu, st))
-    error("weight gradient failed");
+  {
+    // weight gradient: tile shapes 0..3 (conv_wgrad.hip) or its own heuristic (-1); the timing runs
+    // accumulate into the transpose scratch (nweights floats fit: it is sized for the largest layer)
+    float* scratch_dw = net->wt_scratch_gpu;
+    const int wcfg = train_choice(l, 2, d, scratch_dw ? std::vector<int>{-1, 0, 1, 2, 3} : std::vector<int>{-1}, -1,
+        [&](int c) {
+          if (dk_conv_backward_weights_cfg(&d, state.input, l->delta_gpu, scratch_dw, st, c))
+            error("weight gradient (timing) failed");
+        }, st);
+    if (dk_conv_backward_weights_cfg(&d, state.input, l->delta_gpu, l->weight_updates_gpu, st, wcfg))
+      error("weight gradient failed");
+  }
   if (state.delta)
   {
     const int Cg = l->c / l->groups, Mg = l->n / l->groups;
-    float* wt = state.net->wt_scratch_gpu;
-    if (l->size == 3 && l->stride_x == 1 && l->stride_y == 1 && l->pad == 1 && l->dilation == 1 &&
-        l->groups == 1)
+    float* wt = net->wt_scratch_gpu;
+    const bool same3 = l->size == 3 && l->stride_x == 1 && l->stride_y == 1 && l->pad == 1 && l->dilation == 1 &&
+                       l->groups == 1;
+    const bool plain1 = l->size == 1 && l->stride_x == 1 && l->stride_y == 1 && l->pad == 0 && l->groups == 1;
+    if (same3 || plain1)
     {
-      // stride-1 "same" 3x3: the data gradient IS a 3x3/s1/p1 convolution of delta with
-      // the transposed, 180-degree-rotated filters -> the forward kernels (patch-in-LDS
-      // where it applies).  Overwrites prev_delta like the gather path.
-      dk_transpose_weights_flip(l->weights_gpu, wt, Mg, Cg, 3, st);
+      // stride-1 "same" 3x3: the data gradient IS a 3x3/s1/p1 convolution of delta with the transposed,
+      // 180-degree-rotated filters; 1x1/s1: a 1x1 convolution with the transposed matrix -> the forward
+      // kernels (patch-in-LDS / Winograd / LDS-DMA GEMM where they apply).  Overwrites prev_delta like the
+      // gather path.
+      if (same3)
+        dk_transpose_weights_flip(l->weights_gpu, wt, Mg, Cg, 3, st);
+      else
+        dk_transpose_weights(l->weights_gpu, wt, Mg, Cg, 1, st);
       DkConvDesc dd = d;
       dd.c = l->n; dd.h = l->out_h; dd.w = l->out_w; dd.n = l->c;
-      if (dk_conv_forward_cfg(&dd, l->delta_gpu, wt, nullptr, state.delta, nullptr, nullptr, st, -1))
-        error("data gradient (as convolution) failed");
+      const bool wino_ok = train_wino_on() && net->wino_scratch_gpu != nullptr;
+      const int cfg = train_choice(l, 1, dd, forward_candidates(dd, wino_ok), dk_conv_pick_config(&dd),
+          [&](int c) { train_conv(net, dd, l->delta_gpu, wt, state.delta, c, st, "data gradient (as convolution, timing) failed"); }, st);
+      train_conv(net, dd, l->delta_gpu, wt, state.delta, cfg, st, "data gradient (as convolution) failed");
       return;
     }
     for (int g = 0; g < l->groups; ++g)
       dk_transpose_weights(l->weights_gpu + (size_t)g * l->nweights / l->groups,
           wt + (size_t)g * l->nweights / l->groups, Mg, Cg, l->size, st);
-    if (dk_conv_backward_data(&d, l->delta_gpu, wt, state.delta, st))
+    std::vector<int> cands = {-1};
+    for (int c = 0; c < dk_conv_num_gather_configs(); ++c) cands.push_back(c);
+    const int cfg = train_choice(l, 1, d, cands, -1,
+        [&](int c) {
+          if (dk_conv_backward_data_cfg(&d, l->delta_gpu, wt, state.delta, st, c))
+            error("data gradient (timing) failed");
+        }, st);
+    if (dk_conv_backward_data_cfg(&d, l->delta_gpu, wt, state.delta, st, cfg))
       error("data gradient failed");
   }
 }

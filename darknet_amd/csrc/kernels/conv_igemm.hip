@@ -827,6 +827,7 @@ extern "C" __attribute__((visibility("default"))) void DkTestBlockTile(int tiles
 }
 
 int dk_conv_num_configs() { return total_cfgs(); }
+int dk_conv_num_gather_configs() { return g_ncfg; }
 
 const int2* dk_conv_ktab(const DkConvDesc* d, int K, int C, int mode) { return get_plan(d, K, C, mode).ktab; }
 
@@ -844,7 +845,7 @@ extern "C" int dk_conv_forward(const DkConvDesc* d, const float* x, const float*
 
 int dk_conv_forward_cfg(const DkConvDesc* d, const float* x, const float* weights,
     const float* biases, float* y, const float* residual, float* activation_input, void* stream,
-    int cfg_override, int out_ctot, const DkConvDual* dual)
+    int cfg_override, int out_ctot, const DkConvDual* dual, const float* wino_filters)
 {
   if (!d || !x || !weights || !y || d->groups < 1 || d->c % d->groups || d->n % d->groups ||
       d->size < 1 || d->stride_x < 1 || d->stride_y < 1 || d->dilation < 1)
@@ -966,7 +967,7 @@ int dk_conv_forward_cfg(const DkConvDesc* d, const float* x, const float* weight
     // dual output (neither occurs on the inference loads that select it)
     const float* wino_u = (want >= wino_base() && want < total_cfgs() && !activation_input && !dual &&
                               dk_conv_wino_applicable(d, want - wino_base()))
-                              ? dk_conv_wino_lookup(weights)
+                              ? (wino_filters ? wino_filters : dk_conv_wino_lookup(weights))
                               : nullptr;
     if (wino_u)
     {
@@ -1080,6 +1081,12 @@ int dk_conv_forward_cfg(const DkConvDesc* d, const float* x, const float* weight
 extern "C" int dk_conv_backward_data(const DkConvDesc* d, const float* delta, const float* wt,
     float* prev_delta, void* stream)
 {
+  return dk_conv_backward_data_cfg(d, delta, wt, prev_delta, stream, -1);
+}
+
+int dk_conv_backward_data_cfg(const DkConvDesc* d, const float* delta, const float* wt,
+    float* prev_delta, void* stream, int cfg_override)
+{
   if (!d || !delta || !wt || !prev_delta || d->groups < 1 || d->size * d->size > 31)
   {
     fprintf(stderr, "dk_conv_backward_data: invalid arguments\n");
@@ -1130,7 +1137,7 @@ extern "C" int dk_conv_backward_data(const DkConvDesc* d, const float* delta, co
     a.pad = pad; a.dil = d->dilation;
     a.act = DK_LINEAR;
     a.mode = 1;
-    const int ci = pick_cfg(Cg, a.N, d->groups);
+    const int ci = (cfg_override >= 0 && cfg_override < g_ncfg) ? cfg_override : pick_cfg(Cg, a.N, d->groups);
     const TileCfg& c = g_cfgs[ci];
     a.tiles_m = (Cg + c.bm - 1) / c.bm;
     a.tiles_n = (a.N + c.bn - 1) / c.bn;

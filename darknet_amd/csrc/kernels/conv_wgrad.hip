@@ -363,6 +363,12 @@ const WgradCfg g_wcfg[] = {DK_WG(2, 2), DK_WG(1, 2), DK_WG(2, 1), DK_WG(1, 1)};
 extern "C" int dk_conv_backward_weights(const DkConvDesc* d, const float* x, const float* delta,
     float* weight_updates, void* stream)
 {
+  return dk_conv_backward_weights_cfg(d, x, delta, weight_updates, stream, -1);
+}
+
+int dk_conv_backward_weights_cfg(const DkConvDesc* d, const float* x, const float* delta,
+    float* weight_updates, void* stream, int cfg_override)
+{
   if (!d || !x || !delta || !weight_updates || d->groups < 1)
   {
     fprintf(stderr, "dk_conv_backward_weights: invalid arguments\n");
@@ -412,6 +418,8 @@ extern "C" int dk_conv_backward_weights(const DkConvDesc* d, const float* x, con
     // 3x3 layers with 64 (not 128) channels per tap: 64-tap tiles keep the tap-major path available
     if (d->size > 1 && (C % 128) != 0 && (C % 64) == 0)
       ci |= 2;
+    if (cfg_override >= 0 && cfg_override < 4)
+      ci = cfg_override;
     const WgradCfg& c = g_wcfg[ci];
     const int BM = 64 * c.tm, BKO = 64 * c.tk;
     a.tiles_m = (M + BM - 1) / BM;

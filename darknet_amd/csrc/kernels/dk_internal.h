@@ -17,7 +17,17 @@ struct DkConvDual
 };
 int dk_conv_forward_cfg(const DkConvDesc* d, const float* x, const float* weights,
     const float* biases, float* y, const float* residual, float* activation_input, void* stream,
-    int cfg, int out_ctot = 0, const DkConvDual* dual = nullptr);
+    int cfg, int out_ctot = 0, const DkConvDual* dual = nullptr, const float* wino_filters = nullptr);
+// wino_filters != nullptr: the transformed filters (dk_conv_wino_transform_weights) to use when `cfg` is the
+// Winograd configuration, instead of the registry entry of `weights` (training: the filters change every step)
+// dk_conv_backward_data with an explicit gather tile configuration (cfg < 0 or not a gather shape: heuristic)
+int dk_conv_backward_data_cfg(const DkConvDesc* d, const float* delta, const float* wt, float* prev_delta,
+    void* stream, int cfg);
+// number of gather (implicit-GEMM) tile configurations: indices [0, n) of the configuration table
+int dk_conv_num_gather_configs();
+// dk_conv_backward_weights with an explicit tile shape (0..3: 128x128, 64x128, 128x64, 64x64 rows x taps; < 0: heuristic)
+int dk_conv_backward_weights_cfg(const DkConvDesc* d, const float* x, const float* delta, float* weight_updates,
+    void* stream, int cfg);
 int dk_conv_forward_half_strided(const DkConvDesc* d, const float* x, const float* weights,
     const float* biases, float* y, const float* residual, float* activation_input, void* stream,
     int out_ctot);

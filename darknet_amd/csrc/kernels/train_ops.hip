@@ -77,20 +77,66 @@ inline void chan_split(int batch, int filters, int spatial, int* chunks, size_t*
   *chunks = (int)((n + *slice - 1) / *slice);
 }
 
-// The same for kernels that walk ONE (image, channel) plane per workgroup (contiguous memory: 16-byte
-// loads, no per-element index division): cps chunks per plane, `slice` elements (a multiple of 4) each;
-// grid = (cps * batch, filters).
-inline void plane_split(int batch, int filters, int spatial, int* cps, int* slice)
+// Work split of the plane-walking reductions (round 2b): a workgroup of RP threads takes `ipw` whole
+// (image, channel) planes of ONE channel, or one slice of a plane when a plane alone is large, so that it
+// has >= ~8 K elements to stream (several independent 16-byte loads in flight per thread) and pays for ONE
+// block reduction; small layers trade elements per workgroup (down to ~2 K) for >= ~1024 workgroups.
+// grid = (cps * image groups, filters).
+constexpr int RP = 256;
+inline void plane_split2(int batch, int filters, int spatial, int* cps, int* slice, int* ipw)
 {
-  const long long planes = (long long)batch * (filters > 0 ? filters : 1);
-  long long c = 2048 / (planes > 0 ? planes : 1);
-  if (c < 1) c = 1;
-  const long long maxc = ((long long)spatial + 2047) / 2048;  // at least ~2048 elements per workgroup
-  if (c > maxc) c = maxc;
-  int sl = (int)(((long long)spatial + c - 1) / c);
-  sl = (sl + 3) & ~3;
-  *slice = sl;
-  *cps = (spatial + sl - 1) / sl;
+  const long long n = (long long)batch * spatial;          // elements per channel
+  const int f = filters > 0 ? filters : 1;
+  long long wpc = n / 8192;                                 // workgroups per channel
+  long long fill = 1024 / f;
+  if (fill > n / 2048) fill = n / 2048;
+  if (wpc < fill) wpc = fill;
+  if (wpc < 1) wpc = 1;
+  const long long per = (n + wpc - 1) / wpc;                // elements per workgroup
+  if (per >= spatial)
+  {
+    int k = (int)(per / spatial);
+    if (k < 1) k = 1;
+    if (k > batch) k = batch;
+    *ipw = k;
+    *cps = 1;
+    *slice = (spatial + 3) & ~3;
+  }
+  else
+  {
+    int c = (int)((spatial + per - 1) / per);
+    int sl = (spatial + c - 1) / c;
+    sl = (sl + 3) & ~3;
+    *ipw = 1;
+    *slice = sl;
+    *cps = (spatial + sl - 1) / sl;
+  }
+}
+
+// sums NV doubles over the workgroup (RP threads) and adds them to dst[0..NV) with fp64 atomics:
+// wave shuffles, one LDS exchange, one barrier
+template <int NV>
+__device__ __forceinline__ void block_reduce_atomic(double (&v)[NV], double* __restrict__ dst)
+{
+  __shared__ double sh[NV * (RP / 64)];
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_down(v[k], o, 64);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0)
+  {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) sh[k * (RP / 64) + w] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < NV)
+  {
+    double r = 0;
+#pragma unroll
+    for (int i = 0; i < RP / 64; ++i) r += sh[threadIdx.x * (RP / 64) + i];
+    atomicAdd(&dst[threadIdx.x], r);
+  }
 }
 
 __device__ __forceinline__ double block_sum(double v, double* sh)
@@ -127,41 +173,63 @@ __device__ __forceinline__ size_t chan_index(size_t t, int f, int filters, int s
 // atomics; stage 2, one thread per channel: mean = S/N, variance = (Q - S*S/N)/(N-1)
 // (the reference's N-1 denominator, src/blas.c:186; evaluated in double, so the
 // one-pass form loses nothing), rolling statistics .9/.1.
-__global__ void __launch_bounds__(RT) bn_partial_kernel(const float* __restrict__ x, int batch,
-    int filters, int spatial, int cps, int slice, double* __restrict__ scratch)
+__global__ void __launch_bounds__(RP) bn_partial_kernel(const float* __restrict__ x, int batch,
+    int filters, int spatial, int cps, int slice, int ipw, double* __restrict__ scratch)
 {
-  __shared__ double sh[RT / 64];
   const int f = blockIdx.y;
-  const int b = blockIdx.x / cps, ch = blockIdx.x - b * cps;
+  const int bg = blockIdx.x / cps, ch = blockIdx.x - bg * cps;
+  const int b0 = bg * ipw;
+  const int b1 = (b0 + ipw < batch) ? b0 + ipw : batch;
   const int i0 = ch * slice;
   const int i1 = (i0 + slice < spatial) ? i0 + slice : spatial;
-  const float* const px = x + ((size_t)b * filters + f) * spatial;
-  double s = 0, q = 0;
-  if ((spatial & 3) == 0 && (((uintptr_t)x) & 15) == 0)
+  double acc[2] = {0, 0};
+  const bool vec = (spatial & 3) == 0 && (((uintptr_t)x) & 15) == 0;
+  for (int b = b0; b < b1; ++b)
   {
-    for (int i = i0 + 4 * (int)threadIdx.x; i < i1; i += 4 * RT)
+    const float* const px = x + ((size_t)b * filters + f) * spatial;
+    if (vec)
     {
-      const float4 v = *(const float4*)(px + i);
-      s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
-      q += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+      int i = i0 + 4 * (int)threadIdx.x;
+      // four independent 16-byte loads in flight per thread
+      for (; i + 12 * RP < i1; i += 16 * RP)
+      {
+        const float4 v0 = *(const float4*)(px + i);
+        const float4 v1 = *(const float4*)(px + i + 4 * RP);
+        const float4 v2 = *(const float4*)(px + i + 8 * RP);
+        const float4 v3 = *(const float4*)(px + i + 12 * RP);
+        const float4 vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+        {
+          acc[0] += (double)vv[k].x + (double)vv[k].y + (double)vv[k].z + (double)vv[k].w;
+          acc[1] += (double)vv[k].x * vv[k].x + (double)vv[k].y * vv[k].y + (double)vv[k].z * vv[k].z + (double)vv[k].w * vv[k].w;
+        }
+      }
+      for (; i < i1; i += 4 * RP)
+      {
+        const float4 v = *(const float4*)(px + i);
+        acc[0] += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+        acc[1] += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+      }
+    }
+    else
+    {
+      int i = i0 + (int)threadIdx.x;
+      for (; i + RP < i1; i += 2 * RP)
+      {
+        const double v0 = px[i], v1 = px[i + RP];
+        acc[0] += v0 + v1;
+        acc[1] += v0 * v0 + v1 * v1;
+      }
+      for (; i < i1; i += RP)
+      {
+        const double v = px[i];
+        acc[0] += v;
+        acc[1] += v * v;
+      }
     }
   }
-  else
-  {
-    for (int i = i0 + (int)threadIdx.x; i < i1; i += RT)
-    {
-      const double v = px[i];
-      s += v;
-      q += v * v;
-    }
-  }
-  s = block_sum(s, sh);
-  q = block_sum(q, sh);
-  if (threadIdx.x == 0)
-  {
-    atomicAdd(&scratch[2 * f + 0], s);
-    atomicAdd(&scratch[2 * f + 1], q);
-  }
+  block_reduce_atomic<2>(acc, scratch + 2 * f);
 }
 
 __global__ void bn_finalize_kernel(double* __restrict__ scratch, int batch, int filters,
@@ -217,9 +285,7 @@ __global__ void bn_apply_kernel(const float* __restrict__ raw, float* __restrict
   const size_t base = (size_t)plane * spatial;
   if (vec)
   {
-    for (int i = 4 * (blockIdx.y * blockDim.x + threadIdx.x); i < spatial; i += 4 * gridDim.y * blockDim.x)
-    {
-      const float4 v = *(const float4*)(raw + base + i);
+    auto four = [&](const float4 v, int i) {
       float4 xn, pre, o;
       o.x = bn_apply_one(v.x, m, div, sc, bi, act, &xn.x, &pre.x);
       o.y = bn_apply_one(v.y, m, div, sc, bi, act, &xn.y, &pre.y);
@@ -232,7 +298,18 @@ __global__ void bn_apply_kernel(const float* __restrict__ raw, float* __restrict
       if (act_in)
         *(float4*)(act_in + base + i) = pre;
       *(float4*)(out + base + i) = o;
+    };
+    const int step = 4 * gridDim.y * blockDim.x;
+    int i = 4 * (blockIdx.y * blockDim.x + threadIdx.x);
+    // two 16-byte loads in flight per thread
+    for (; i + step < spatial; i += 2 * step)
+    {
+      const float4 va = *(const float4*)(raw + base + i);
+      const float4 vb = *(const float4*)(raw + base + i + step);
+      four(va, i);
+      four(vb, i + step);
     }
+    for (; i < spatial; i += step) four(*(const float4*)(raw + base + i), i);
     return;
   }
   for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < spatial; i += gridDim.y * blockDim.x)
@@ -418,79 +495,121 @@ __device__ __forceinline__ BnRecompute bn_recompute(float x, float delta, float 
   return r;
 }
 
-__global__ void __launch_bounds__(RT) bn_act_partial_kernel(const float* __restrict__ delta,
+__global__ void __launch_bounds__(RP) bn_act_partial_kernel(const float* __restrict__ delta,
     const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ variance,
     const float* __restrict__ scales, const float* __restrict__ biases, int batch, int filters,
-    int spatial, int cps, int slice, double* __restrict__ scratch, int act)
+    int spatial, int cps, int slice, int ipw, double* __restrict__ scratch, int act)
 {
-  __shared__ double sh[RT / 64];
   const int f = blockIdx.y;
-  const int b = blockIdx.x / cps, ch = blockIdx.x - b * cps;
+  const int bg = blockIdx.x / cps, ch = blockIdx.x - bg * cps;
+  const int b0 = bg * ipw;
+  const int b1 = (b0 + ipw < batch) ? b0 + ipw : batch;
   const int i0 = ch * slice;
   const int i1 = (i0 + slice < spatial) ? i0 + slice : spatial;
-  const size_t base = ((size_t)b * filters + f) * spatial;
-  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  double acc[4] = {0, 0, 0, 0};
   const float sc = scales[f], bi = biases[f], m = mean[f];
   const float div = sqrtf(variance[f] + .000001f);
   auto one = [&](float xv, float dv) {
     const BnRecompute r = bn_recompute(xv, dv, m, div, sc, bi, act);
-    s0 += r.d;
-    s1 += r.d * r.xn;
+    acc[0] += r.d;
+    acc[1] += r.d * r.xn;
     const float ds = r.d * sc;
-    s2 += ds;
-    s3 += ds * (xv - m);
+    acc[2] += ds;
+    acc[3] += ds * (xv - m);
   };
-  if ((spatial & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)delta)) & 15) == 0)
+  const bool vec = (spatial & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)delta)) & 15) == 0;
+  for (int b = b0; b < b1; ++b)
   {
-    for (int i = i0 + 4 * (int)threadIdx.x; i < i1; i += 4 * RT)
+    const size_t base = ((size_t)b * filters + f) * spatial;
+    if (vec)
     {
-      const float4 xv = *(const float4*)(x + base + i);
-      const float4 dv = *(const float4*)(delta + base + i);
-      one(xv.x, dv.x);
-      one(xv.y, dv.y);
-      one(xv.z, dv.z);
-      one(xv.w, dv.w);
+      int i = i0 + 4 * (int)threadIdx.x;
+      // two planes' worth of 16-byte loads (x and delta, two positions) in flight per thread
+      for (; i + 4 * RP < i1; i += 8 * RP)
+      {
+        const float4 xa = *(const float4*)(x + base + i);
+        const float4 da = *(const float4*)(delta + base + i);
+        const float4 xb = *(const float4*)(x + base + i + 4 * RP);
+        const float4 db = *(const float4*)(delta + base + i + 4 * RP);
+        one(xa.x, da.x); one(xa.y, da.y); one(xa.z, da.z); one(xa.w, da.w);
+        one(xb.x, db.x); one(xb.y, db.y); one(xb.z, db.z); one(xb.w, db.w);
+      }
+      for (; i < i1; i += 4 * RP)
+      {
+        const float4 xv = *(const float4*)(x + base + i);
+        const float4 dv = *(const float4*)(delta + base + i);
+        one(xv.x, dv.x); one(xv.y, dv.y); one(xv.z, dv.z); one(xv.w, dv.w);
+      }
+    }
+    else
+    {
+      int i = i0 + (int)threadIdx.x;
+      for (; i + RP < i1; i += 2 * RP)
+      {
+        const float x0 = x[base + i], d0 = delta[base + i], x1 = x[base + i + RP], d1 = delta[base + i + RP];
+        one(x0, d0);
+        one(x1, d1);
+      }
+      for (; i < i1; i += RP) one(x[base + i], delta[base + i]);
     }
   }
-  else
-  {
-    for (int i = i0 + (int)threadIdx.x; i < i1; i += RT) one(x[base + i], delta[base + i]);
-  }
-  s0 = block_sum(s0, sh);
-  s1 = block_sum(s1, sh);
-  s2 = block_sum(s2, sh);
-  s3 = block_sum(s3, sh);
-  if (threadIdx.x == 0)
-  {
-    atomicAdd(&scratch[4 * f + 0], s0);
-    atomicAdd(&scratch[4 * f + 1], s1);
-    atomicAdd(&scratch[4 * f + 2], s2);
-    atomicAdd(&scratch[4 * f + 3], s3);
-  }
+  block_reduce_atomic<4>(acc, scratch + 4 * f);
 }
 
-// grid (batch*filters, chunks): one (image, channel) plane per blockIdx.x -> no per-element division
+// grid (batch*filters, chunks): one (image, channel) plane per blockIdx.x -> no per-element division.
+// normalize_delta_cpu's expression  ds * 1. / (sqrt(var) + .00001f) + vd * 2. * (x - m) / nb + md / nb  is
+// evaluated in double there (the literals promote it); here the three per-channel factors are formed once in
+// double and the element costs one fp64 multiply and one fma instead of two fp64 divisions -- the double
+// result differs by <= 2 ulp(double) before the final rounding to float.
 __global__ void bn_act_delta_kernel(float* __restrict__ delta, const float* __restrict__ x,
     const float* __restrict__ mean, const float* __restrict__ variance,
     const float* __restrict__ mean_delta, const float* __restrict__ variance_delta,
     const float* __restrict__ scales, const float* __restrict__ biases, int batch, int filters,
-    int spatial, int act)
+    int spatial, int act, int vec)
 {
   const int plane = blockIdx.x;
   const int f = plane % filters;
   const int nb = spatial * batch;
   const float sc = scales[f], bi = biases[f], m = mean[f], var = variance[f];
   const float div = sqrtf(var + .000001f);
-  const float vd = variance_delta[f], md = mean_delta[f];
+  const double ka = 1. / (double)(sqrtf(var) + .00001f);
+  const double kb = (double)variance_delta[f] * 2. / (double)nb;
+  const double kc = (double)(mean_delta[f] / nb);
   float* dp = delta + (size_t)plane * spatial;
   const float* xp = x + (size_t)plane * spatial;
-  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < spatial; i += gridDim.y * blockDim.x)
-  {
-    const float xv = xp[i];
-    const BnRecompute r = bn_recompute(xv, dp[i], m, div, sc, bi, act);
+  auto one = [&](float xv, float dv) -> float {
+    const BnRecompute r = bn_recompute(xv, dv, m, div, sc, bi, act);
     const float ds = r.d * sc;
-    dp[i] = ds * 1. / (sqrtf(var) + .00001f) + vd * 2. * (xv - m) / nb + md / nb;
+    return (float)((double)ds * ka + kb * (double)(xv - m) + kc);
+  };
+  if (vec)
+  {
+    const int step = 4 * gridDim.y * blockDim.x;
+    int i = 4 * (blockIdx.y * blockDim.x + threadIdx.x);
+    for (; i + step < spatial; i += 2 * step)
+    {
+      const float4 xa = *(const float4*)(xp + i);
+      const float4 da = *(const float4*)(dp + i);
+      const float4 xb = *(const float4*)(xp + i + step);
+      const float4 db = *(const float4*)(dp + i + step);
+      float4 oa, ob;
+      oa.x = one(xa.x, da.x); oa.y = one(xa.y, da.y); oa.z = one(xa.z, da.z); oa.w = one(xa.w, da.w);
+      ob.x = one(xb.x, db.x); ob.y = one(xb.y, db.y); ob.z = one(xb.z, db.z); ob.w = one(xb.w, db.w);
+      *(float4*)(dp + i) = oa;
+      *(float4*)(dp + i + step) = ob;
+    }
+    for (; i < spatial; i += step)
+    {
+      const float4 xv = *(const float4*)(xp + i);
+      const float4 dv = *(const float4*)(dp + i);
+      float4 o;
+      o.x = one(xv.x, dv.x); o.y = one(xv.y, dv.y); o.z = one(xv.z, dv.z); o.w = one(xv.w, dv.w);
+      *(float4*)(dp + i) = o;
+    }
+    return;
   }
+  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < spatial; i += gridDim.y * blockDim.x)
+    dp[i] = one(xp[i], dp[i]);
 }
 
 // ---- backward of the glue layers ----------------------------------------------------
@@ -683,10 +802,10 @@ extern "C" int dk_bn_forward_train(const float* raw, float* x_save, float* x_nor
   {
     hipStream_t st = S(stream);
     double* scratch = chan_scratch(filters, st);
-    int cps, slice;
-    plane_split(batch, filters, spatial, &cps, &slice);
-    hipLaunchKernelGGL(bn_partial_kernel, dim3(cps * batch, filters), dim3(RT), 0, st, raw, batch,
-        filters, spatial, cps, slice, scratch);
+    int cps, slice, ipw;
+    plane_split2(batch, filters, spatial, &cps, &slice, &ipw);
+    hipLaunchKernelGGL(bn_partial_kernel, dim3(cps * ((batch + ipw - 1) / ipw), filters), dim3(RP), 0, st, raw, batch,
+        filters, spatial, cps, slice, ipw, scratch);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((filters + 255) / 256), dim3(256), 0, st, scratch,
         batch, filters, spatial, mean, variance, rolling_mean, rolling_variance);
     CHECK_HIP(hipPeekAtLastError());
@@ -696,7 +815,7 @@ extern "C" int dk_bn_forward_train(const float* raw, float* x_save, float* x_nor
     float* const xn = train ? x_norm : nullptr;
     const uintptr_t al = (uintptr_t)raw | (uintptr_t)out | (uintptr_t)xs | (uintptr_t)xn | (uintptr_t)act_in;
     const int vec = ((spatial & 3) == 0 && (al & 15) == 0) ? 1 : 0;
-    int gx = (spatial + (vec ? 4095 : 1023)) / (vec ? 4096 : 1024);
+    int gx = (spatial + (vec ? 8191 : 1023)) / (vec ? 8192 : 1024);
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(bn_apply_kernel, dim3(batch * filters, gx), dim3(256), 0, S(stream), raw, xs, xn, act_in, out,
         train ? mean : rolling_mean, train ? variance : rolling_variance, scales, biases, filters, spatial,
@@ -777,16 +896,18 @@ extern "C" int dk_bn_act_backward(float* delta, const float* x, const float* mea
   if (activation == DK_MISH && dk_fast_mish_enabled())
     activation |= DK_ACT_FAST;
   double* scratch = chan_scratch(filters, st);
-  int cps, slice;
-  plane_split(batch, filters, spatial, &cps, &slice);
-  hipLaunchKernelGGL(bn_act_partial_kernel, dim3(cps * batch, filters), dim3(RT), 0, st, delta, x, mean,
-      variance, scales, biases, batch, filters, spatial, cps, slice, scratch, activation);
+  int cps, slice, ipw;
+  plane_split2(batch, filters, spatial, &cps, &slice, &ipw);
+  hipLaunchKernelGGL(bn_act_partial_kernel, dim3(cps * ((batch + ipw - 1) / ipw), filters), dim3(RP), 0, st, delta, x, mean,
+      variance, scales, biases, batch, filters, spatial, cps, slice, ipw, scratch, activation);
   hipLaunchKernelGGL(chan_finalize_kernel, dim3((filters + 255) / 256), dim3(256), 0, st, scratch,
       variance, filters, bias_updates, scale_updates, mean_delta, variance_delta, 1);
-  int gx = (spatial + 1023) / 1024;
+  const int vec = ((spatial & 3) == 0 && ((((uintptr_t)delta) | ((uintptr_t)x)) & 15) == 0) ? 1 : 0;
+  // one 256-thread workgroup streams up to 8 K elements of its plane (two 16-byte positions in flight per thread)
+  int gx = vec ? (spatial + 8191) / 8192 : (spatial + 1023) / 1024;
   if (gx > 64) gx = 64;
   hipLaunchKernelGGL(bn_act_delta_kernel, dim3(batch * filters, gx), dim3(256), 0, st, delta, x, mean,
-      variance, mean_delta, variance_delta, scales, biases, batch, filters, spatial, activation);
+      variance, mean_delta, variance_delta, scales, biases, batch, filters, spatial, activation, vec);
   CHECK_HIP(hipPeekAtLastError());
   return 0;
 }

@@ -241,6 +241,8 @@ struct layer
   struct layer* dual_peer; /* the other conv of a dual launch (master <-> slave), or NULL */
   void* weights_half_gpu; /* fp16 weights packed for conv3x3_direct_f16 (inference plan with cudnn_half), or NULL */
   float* weights_wino_gpu; /* filters transformed for conv3x3_wino_f32 (inference plan, DkSetWinograd), or NULL */
+  int train_plan[3];     /* train step: forward / data-gradient / weight-gradient tile configuration + 2, timed on the
+                          * layer's own tensors at the first step (1 = the heuristic, 0 = not chosen yet) */
   int delta_in_arena;    /* delta_gpu points into net->delta_arena_gpu (not freed per layer) */
   int buffers_aliased;   /* [dropout]: output_gpu / delta_gpu are the previous layer's (not freed here) */
   float* out_view;       /* producer: where the output really goes (a channel slice), or NULL */
@@ -294,6 +296,7 @@ struct Network
   void* graph_exec;      /* hipGraphExec_t of the captured forward, or NULL */
   int graph_batch;
   float* wt_scratch_gpu; /* transposed weights of the layer whose data gradient is running */
+  float* wino_scratch_gpu; /* train: Winograd-transformed filters of the layer that is running (they change every step) */
   /* device-side detection extraction and u8 input staging (see DkSetPullHeads, DkNetworkPredictU8) */
   float* cand_gpu;       /* candidate records written by dk_yolo_compact */
   int* cand_counter_gpu;

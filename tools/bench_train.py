@@ -8,6 +8,31 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tools")]
 
 
+def train_tune_summary(dk, net):
+    """What the first step's kernel timing chose: seconds spent and, per GEMM of the step (forward / data gradient /
+    weight gradient), how many layers run which configuration."""
+    L, C = dk.lib(), dk.C
+    L.DkTrainTuneSeconds.restype = C.c_double
+    L.DkLayerTrainCfg.restype = C.c_int
+    L.DkLayerTrainCfg.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.dk_conv_config_name.restype = C.c_char_p
+    L.dk_conv_config_name.argtypes = [C.c_int]
+    out = {"seconds": L.DkTrainTuneSeconds()}
+    for kind, name in enumerate(("forward", "dgrad", "wgrad")):
+        hist = {}
+        for i in range(net.n):
+            c = L.DkLayerTrainCfg(net.p, i, kind)
+            if c < -1:
+                continue
+            if kind == 2:
+                key = {-1: "heuristic", 0: "128x128", 1: "64x128", 2: "128x64", 3: "64x64"}[c]
+            else:
+                key = "heuristic" if c < 0 else (L.dk_conv_config_name(c) or b"?").decode()
+            hist[key] = hist.get(key, 0) + 1
+        out[name] = hist
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,7 +106,8 @@ def main():
                           "frac_of_fp32_mfma_roofline": (rate * 3 * gf_img * 1e9 / (ctx.world * 157.3e12)) if gf_img else None,
                           "config": {"workload": "%s.cfg %dx%d batch=%d/GPU train step (forward with batch statistics, host yolo loss, "
                                                  "backward, gradient all-reduce, SGD)" % (a.cfg, net.w, net.h, a.batch)},
-                          "grad_bucket_mfloats": tr.bucket.numel() / 1e6, "roofline": roofline}))
+                          "grad_bucket_mfloats": tr.bucket.numel() / 1e6, "roofline": roofline,
+                          "train_tune": train_tune_summary(dk, net)}))
     net.close(); ctx.close()
 
 
