@@ -173,12 +173,72 @@ void train_conv(Network* net, const DkConvDesc& d, const float* x, const float* 
   if (dk_conv_forward_cfg(&d, x, w, nullptr, y, nullptr, nullptr, st, cfg, 0, nullptr, u))
     error(what);
 }
+
+// DK_TRAIN_LAYERS=1 (diagnostics, tools/train_layers.py): every GEMM of the step is bracketed by events and
+// DkTrainLayerReport() returns "layer kind cfg gflop ms" lines for the steps since the last call
+struct LayerRec
+{
+  int layer, kind, cfg;
+  double gflop;
+  hipEvent_t e0, e1;
+};
+std::vector<LayerRec> g_layer_recs;
+std::mutex g_layer_mu;
+bool train_layers_on()
+{
+  static const int v = getenv("DK_TRAIN_LAYERS") ? atoi(getenv("DK_TRAIN_LAYERS")) : 0;
+  return v != 0;
+}
+struct LayerScope
+{
+  LayerRec r;
+  hipStream_t st;
+  bool on;
+  LayerScope(const layer* l, int index, int kind, int cfg, hipStream_t s) : st(s), on(train_layers_on())
+  {
+    if (!on)
+      return;
+    r.layer = index; r.kind = kind; r.cfg = cfg;
+    r.gflop = 2.0 * l->n * (double)(l->c / l->groups) * l->size * l->size * l->out_h * l->out_w * l->batch / 1e9;
+    CHECK_HIP(hipEventCreate(&r.e0));
+    CHECK_HIP(hipEventCreate(&r.e1));
+    CHECK_HIP(hipEventRecord(r.e0, st));
+  }
+  ~LayerScope()
+  {
+    if (!on)
+      return;
+    CHECK_HIP(hipEventRecord(r.e1, st));
+    std::lock_guard<std::mutex> lk(g_layer_mu);
+    g_layer_recs.push_back(r);
+  }
+};
 }  // namespace
 
 extern "C" LIB_API double DkTrainTuneSeconds()
 {
   std::lock_guard<std::mutex> lk(g_tune.mu);
   return g_tune.seconds;
+}
+// text report of the GEMM timings recorded since the last call (needs DK_TRAIN_LAYERS=1); returns the number of
+// bytes written (0: nothing recorded).  Synchronises the stream.
+extern "C" LIB_API int DkTrainLayerReport(char* out, int cap)
+{
+  CHECK_HIP(hipStreamSynchronize(get_cuda_stream()));
+  std::lock_guard<std::mutex> lk(g_layer_mu);
+  int n = 0;
+  for (LayerRec& r : g_layer_recs)
+  {
+    float ms = 0;
+    CHECK_HIP(hipEventSynchronize(r.e1));
+    CHECK_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+    if (out && n < cap - 96)
+      n += snprintf(out + n, cap - n, "%d %d %d %.4f %.5f\n", r.layer, r.kind, r.cfg, r.gflop, ms);
+  }
+  g_layer_recs.clear();
+  return n;
 }
 extern "C" LIB_API int DkLayerTrainCfg(Network* net, int i, int kind)
 {
@@ -209,6 +269,7 @@ void ForwardConvTrainGpu(layer* l, NetworkState state)
     const float* x = state.input;
     cfg = train_choice(l, 0, d, forward_candidates(d, wino_ok), dk_conv_pick_config(&d),
         [&](int c) { train_conv(net, d, x, l->weights_gpu, raw, c, st, "ForwardConvolutionalLayerGpu (train, timing) failed"); }, st);
+    LayerScope ls(l, state.index, 0, cfg, st);
     train_conv(net, d, x, l->weights_gpu, raw, cfg, st, "ForwardConvolutionalLayerGpu (train) failed");
   }
   else if (dk_conv_forward_cfg(&d, state.input, l->weights_gpu, nullptr, raw, nullptr, nullptr, st, -1))
@@ -252,6 +313,7 @@ void BackwardConvolutionalLayerGpu(layer* l, NetworkState state)
           if (dk_conv_backward_weights_cfg(&d, state.input, l->delta_gpu, scratch_dw, st, c))
             error("weight gradient (timing) failed");
         }, st);
+    LayerScope ls(l, state.index, 2, wcfg, st);
     if (dk_conv_backward_weights_cfg(&d, state.input, l->delta_gpu, l->weight_updates_gpu, st, wcfg))
       error("weight gradient failed");
   }
@@ -277,20 +339,27 @@ void BackwardConvolutionalLayerGpu(layer* l, NetworkState state)
       const bool wino_ok = train_wino_on() && net->wino_scratch_gpu != nullptr;
       const int cfg = train_choice(l, 1, dd, forward_candidates(dd, wino_ok), dk_conv_pick_config(&dd),
           [&](int c) { train_conv(net, dd, l->delta_gpu, wt, state.delta, c, st, "data gradient (as convolution, timing) failed"); }, st);
+      LayerScope ls(l, state.index, 1, cfg, st);
       train_conv(net, dd, l->delta_gpu, wt, state.delta, cfg, st, "data gradient (as convolution) failed");
       return;
     }
-    for (int g = 0; g < l->groups; ++g)
-      dk_transpose_weights(l->weights_gpu + (size_t)g * l->nweights / l->groups,
-          wt + (size_t)g * l->nweights / l->groups, Mg, Cg, l->size, st);
+    // stride-2 layers: parity-class form (tap-major contraction index, only the matching taps are visited)
+    const int tapmajor = dk_conv_dgrad_tapmajor(&d) ? 1 : 0;
+    if (tapmajor)
+      dk_transpose_weights_tapmajor(l->weights_gpu, wt, Mg, Cg, l->size, st);
+    else
+      for (int g = 0; g < l->groups; ++g)
+        dk_transpose_weights(l->weights_gpu + (size_t)g * l->nweights / l->groups,
+            wt + (size_t)g * l->nweights / l->groups, Mg, Cg, l->size, st);
     std::vector<int> cands = {-1};
     for (int c = 0; c < dk_conv_num_gather_configs(); ++c) cands.push_back(c);
     const int cfg = train_choice(l, 1, d, cands, -1,
         [&](int c) {
-          if (dk_conv_backward_data_cfg(&d, l->delta_gpu, wt, state.delta, st, c))
+          if (dk_conv_backward_data_cfg(&d, l->delta_gpu, wt, state.delta, st, c, tapmajor))
             error("data gradient (timing) failed");
         }, st);
-    if (dk_conv_backward_data_cfg(&d, l->delta_gpu, wt, state.delta, st, cfg))
+    LayerScope ls(l, state.index, 1, cfg, st);
+    if (dk_conv_backward_data_cfg(&d, l->delta_gpu, wt, state.delta, st, cfg, tapmajor))
       error("data gradient failed");
   }
 }

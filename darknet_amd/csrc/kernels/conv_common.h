@@ -32,7 +32,12 @@ struct ConvArgs
   int size, stride_x, stride_y, pad, dil;  // pad = l->pad*dilation
   int act;
   int tiles_m, tiles_n, groups;
-  int mode;          // 0 forward gather; 1 data-gradient gather (x = delta, H/W = delta dims, OH/OW = input dims)
+  int mode;          // 0 forward gather; 1 data-gradient gather (x = delta, H/W = delta dims, OH/OW = input dims);
+                     // 2 data gradient of a stride-2 layer by parity class (see conv_par_pixel)
+  // mode 2: the pixel index is class-major, n = cls * par_ncls + r with cls = 2*(oy&1) + (ox&1) and r < par_count
+  // running over (image, oy/2, ox/2); par_ncls = par_count rounded up to the tile width, N = 4 * par_ncls
+  int par_ncls, par_count, par_hw2, par_w2;
+  double inv_par_ncls, inv_par_hw2, inv_par_w2;
   // reciprocals of the divisors the kernels' index arithmetic uses (set by conv_args_finish):
   // an integer division costs ~40 VALU instructions, fdiv() four
   double inv_OHW, inv_OW, inv_tiles_m, inv_per_group, inv_HW, inv_W, inv_He;
@@ -146,6 +151,9 @@ inline void conv_args_finish(ConvArgs& a)
   a.inv_HW = 1.0 / ((double)a.H * a.W > 0 ? (double)a.H * a.W : 1.0);
   a.inv_W = 1.0 / (a.W > 0 ? a.W : 1);
   a.inv_He = 1.0 / (a.H + 2);
+  a.inv_par_ncls = 1.0 / (a.par_ncls > 0 ? a.par_ncls : 1);
+  a.inv_par_hw2 = 1.0 / (a.par_hw2 > 0 ? a.par_hw2 : 1);
+  a.inv_par_w2 = 1.0 / (a.par_w2 > 0 ? a.par_w2 : 1);
 }
 
 __device__ __forceinline__ float ld_buf(__amdgpu_buffer_rsrc_t r, unsigned byte_off)
@@ -162,6 +170,26 @@ __device__ __forceinline__ float4 ld_buf4(__amdgpu_buffer_rsrc_t r, unsigned byt
 }
 
 constexpr unsigned OOB = 0x80000000u;  // ORed into a byte offset: always outside the buffer
+
+// mode 2 (data gradient of a stride-2 convolution): an input pixel only receives the taps whose parity matches
+// its own, so the pixels are enumerated parity class by parity class -- every pixel tile then belongs to ONE
+// class, its valid taps are the same for the whole workgroup, and (with the contraction index ordered tap-major)
+// the K tiles of the other taps are skipped instead of being multiplied by gathered zeros (9 of 36 tap-pixel
+// pairs do work for a 3x3 / stride-2 layer).  Returns false for the padding slots at the end of a class.
+__device__ __forceinline__ bool conv_par_pixel(const ConvArgs& p, int n, int& b, int& oy, int& ox)
+{
+  const int cls = fdiv(n, p.par_ncls, p.inv_par_ncls);
+  const int r = n - cls * p.par_ncls;
+  const bool ok = r < p.par_count;
+  const int rr = ok ? r : 0;
+  b = fdiv(rr, p.par_hw2, p.inv_par_hw2);
+  const int q = rr - b * p.par_hw2;
+  const int j = fdiv(q, p.par_w2, p.inv_par_w2);
+  const int i = q - j * p.par_w2;
+  oy = 2 * j + (cls >> 1);
+  ox = 2 * i + (cls & 1);
+  return ok;
+}
 
 // --------------------------------------------------------------------------
 // Shared epilogue of the implicit-GEMM kernels: bias + activation (+ residual,
@@ -185,16 +213,28 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
   __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc((void*)p.act_in, 0, p.act_in ? p.y_bytes : 0u, 0x00020000);
   const bool has_res = p.residual != nullptr, has_ain = p.act_in != nullptr;
   const int act = p.act;
-  const bool full_tile = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+  bool full_tile = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+  if (p.mode == 2)   // class-major pixels: the tail of a class is padding
+    full_tile = full_tile && (n0 - fdiv(n0, p.par_ncls, p.inv_par_ncls) * p.par_ncls + BN <= p.par_count);
   unsigned obase[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j)
   {
     const int n = n0 + wn * WN + j * 32 + l31;
-    const bool nv = n < p.N;
+    bool nv = n < p.N;
     const int nn = nv ? n : 0;
-    const int b = fdiv(nn, p.OHW, p.inv_OHW);
-    const int pix = nn - b * p.OHW;
+    int b, pix;
+    if (p.mode == 2)
+    {
+      int oy, ox;
+      nv = conv_par_pixel(p, nn, b, oy, ox) && nv;
+      pix = oy * p.OW + ox;
+    }
+    else
+    {
+      b = fdiv(nn, p.OHW, p.inv_OHW);
+      pix = nn - b * p.OHW;
+    }
     obase[j] = nv ? (unsigned)((b * mtot + g * p.M) * p.OHW + pix) * 4u : 0xFFFFFFFFu;
   }
   const unsigned row_bytes = (unsigned)p.OHW * 4u;

@@ -138,12 +138,18 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
   else
   {
     const int n = n0 + bn_l;
-    const bool nv = n < p.N;
+    bool nv = n < p.N;
     const int nn = nv ? n : 0;
-    const int b = fdiv(nn, p.OHW, p.inv_OHW);
-    const int pix = nn - b * p.OHW;
-    const int oy = fdiv(pix, p.OW, p.inv_OW);
-    const int ox = pix - oy * p.OW;
+    int b, oy, ox;
+    if (p.mode == 2)
+      nv = conv_par_pixel(p, nn, b, oy, ox) && nv;
+    else
+    {
+      b = fdiv(nn, p.OHW, p.inv_OHW);
+      const int pix = nn - b * p.OHW;
+      oy = fdiv(pix, p.OW, p.inv_OW);
+      ox = pix - oy * p.OW;
+    }
     if (p.mode == 0)
     {
       const int iy0 = oy * p.stride_y - p.pad;
@@ -337,8 +343,39 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nkt = (K + BK - 1) / BK;
+  int nkt = (K + BK - 1) / BK;
   const int l31 = lane & 31, lh = lane >> 5;
+
+  // mode 2: only the K tiles of this class's taps are visited.  The contraction index is tap-major there
+  // (k = t * C + m, C = filters of the layer, a multiple of BK), so a K tile lies inside one tap; par_taps
+  // packs the taps whose parity matches the class (4 bits each), kv_* walk them in launch order.
+  unsigned long long par_taps = 0;
+  int par_tpt = 1, kv_tap = 0, kv_w = 0;
+  if (p.mode == 2)
+  {
+    const int cls = fdiv(n0, p.par_ncls, p.inv_par_ncls);
+    const int ry = ((cls >> 1) + p.pad) & 1, rx = ((cls & 1) + p.pad) & 1;
+    int nvt = 0;
+    for (int kh = 0; kh < p.size; ++kh)
+      for (int kw = 0; kw < p.size; ++kw)
+        if (((kh * p.dil) & 1) == ry && ((kw * p.dil) & 1) == rx)
+          par_taps |= (unsigned long long)(kh * p.size + kw) << (4 * nvt++);
+    par_tpt = p.C / BK;
+    nkt = nvt * par_tpt;
+  }
+  // k0 of the kt-th K tile; tiles are requested in ascending order, each exactly once
+  auto k0_of = [&](int kt) -> int {
+    if (p.mode != 2)
+      return kt * BK;
+    const int t = (int)((par_taps >> (4 * kv_tap)) & 15ull);
+    const int k0 = t * p.C + kv_w * BK;
+    if (++kv_w == par_tpt)
+    {
+      kv_w = 0;
+      ++kv_tap;
+    }
+    return k0;
+  };
 
   // MFMA step s contracts k = 2s (lanes 0-31) and 2s+1 (lanes 32-63): every output
   // accumulates its K products in ascending k, like the reference's gemm_nn
@@ -372,16 +409,18 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
     }
   };
 
+  if (nkt > 0)
+  {
   if (PF == 1)
   {
-    load_tile(0, I0{});
+    load_tile(k0_of(0), I0{});
     store_tile(lds, I0{});
     DK_BARRIER();
     for (int kt = 0; kt < nkt; ++kt)
     {
       const bool more = (kt + 1) < nkt;
       if (more)
-        load_tile((kt + 1) * BK, I0{});
+        load_tile(k0_of(kt + 1), I0{});
       compute(lds + (kt & 1) * STAGE);
       if (more)
         store_tile(lds + ((kt + 1) & 1) * STAGE, I0{});
@@ -391,15 +430,15 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
   else
   {
     // two register sets: tile t lives in set t%2 until it is written to LDS buffer t%2
-    load_tile(0, I0{});
+    load_tile(k0_of(0), I0{});
     if (nkt > 1)
-      load_tile(BK, I1{});
+      load_tile(k0_of(1), I1{});
     store_tile(lds, I0{});
     DK_BARRIER();
     for (int kt = 0; kt < nkt; kt += 2)
     {
       if (kt + 2 < nkt)
-        load_tile((kt + 2) * BK, I0{});
+        load_tile(k0_of(kt + 2), I0{});
       compute(lds);
       if (kt + 1 < nkt)
         store_tile(lds + STAGE, I1{});
@@ -407,12 +446,13 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
       if (kt + 1 >= nkt)
         break;
       if (kt + 3 < nkt)
-        load_tile((kt + 3) * BK, I1{});
+        load_tile(k0_of(kt + 3), I1{});
       compute(lds + STAGE);
       if (kt + 2 < nkt)
         store_tile(lds, I0{});
       DK_BARRIER();
     }
+  }
   }
 
   if (DK_ABL & 1)
@@ -603,7 +643,7 @@ Plan& get_plan(const DkConvDesc* d, int K, int C, int mode = 0)
   memset(&key, 0, sizeof(key));
   key.v[0] = d->c; key.v[1] = d->h; key.v[2] = d->w; key.v[3] = d->groups;
   key.v[4] = d->size; key.v[5] = d->dilation; key.v[6] = mode;
-  if (mode == 1)
+  if (mode >= 1)
   {
     key.v[7] = d->stride_x; key.v[8] = d->stride_y; key.v[9] = d->n;
   }
@@ -622,6 +662,17 @@ Plan& get_plan(const DkConvDesc* d, int K, int C, int mode = 0)
         const int c = k / ss, t = k % ss, kh = t / d->size, kw = t % d->size;
         h[k].x = (c * d->h * d->w + kh * d->dilation * d->w + kw * d->dilation) * 4;  // bytes
         h[k].y = 31 - t;  // left shift that brings tap t's bit to the sign position
+      }
+      else if (k < K && mode == 2)
+      {
+        // data gradient, tap-major contraction index k = t * (n/groups) + m (parity-class launches)
+        const int keff = d->dilation * (d->size - 1) + 1, pd = d->pad * d->dilation;
+        const int oh = (d->h + 2 * pd - keff) / d->stride_y + 1;
+        const int ow = (d->w + 2 * pd - keff) / d->stride_x + 1;
+        const int t = k / C, m = k % C, kh = t / d->size, kw = t % d->size;   // C = filters per group here
+        const int uy = (kh * d->dilation) / d->stride_y, ux = (kw * d->dilation) / d->stride_x;
+        h[k].x = (m * oh * ow - uy * ow - ux) * 4;
+        h[k].y = 31 - t;
       }
       else if (k < K)
       {
@@ -1081,11 +1132,31 @@ int dk_conv_forward_cfg(const DkConvDesc* d, const float* x, const float* weight
 extern "C" int dk_conv_backward_data(const DkConvDesc* d, const float* delta, const float* wt,
     float* prev_delta, void* stream)
 {
-  return dk_conv_backward_data_cfg(d, delta, wt, prev_delta, stream, -1);
+  return dk_conv_backward_data_cfg(d, delta, wt, prev_delta, stream, -1, 0);
+}
+
+extern "C" int dk_conv_backward_data_tapmajor(const DkConvDesc* d, const float* delta, const float* wt_tapmajor,
+    float* prev_delta, void* stream)
+{
+  if (!d || !dk_conv_dgrad_tapmajor(d))
+  {
+    fprintf(stderr, "dk_conv_backward_data_tapmajor: the layer does not take the parity-class form\n");
+    return 1;
+  }
+  return dk_conv_backward_data_cfg(d, delta, wt_tapmajor, prev_delta, stream, -1, 1);
+}
+
+// true when the data gradient of this layer takes the parity-class form (mode 2 of the gather kernel): stride 2 in
+// both directions, even input dimensions, one group, filters a multiple of the deepest K tile
+bool dk_conv_dgrad_tapmajor(const DkConvDesc* d)
+{
+  static const bool on = !(getenv("DK_DGRAD_PARITY") && !atoi(getenv("DK_DGRAD_PARITY")));
+  return on && d->stride_x == 2 && d->stride_y == 2 && d->dilation == 1 && d->groups == 1 && d->size > 1 && d->size < 4 &&
+         d->h % 2 == 0 && d->w % 2 == 0 && d->n % 32 == 0;
 }
 
 int dk_conv_backward_data_cfg(const DkConvDesc* d, const float* delta, const float* wt,
-    float* prev_delta, void* stream, int cfg_override)
+    float* prev_delta, void* stream, int cfg_override, int wt_tapmajor)
 {
   if (!d || !delta || !wt || !prev_delta || d->groups < 1 || d->size * d->size > 31)
   {
@@ -1114,7 +1185,13 @@ int dk_conv_backward_data_cfg(const DkConvDesc* d, const float* delta, const flo
       return 1;
     }
   }
-  Plan& pl = get_plan(d, K, Mg, 1);
+  const bool par = wt_tapmajor != 0;
+  if (par && !dk_conv_dgrad_tapmajor(d))
+  {
+    fprintf(stderr, "dk_conv_backward_data: tap-major weights given for a layer that does not take the parity-class form\n");
+    return 1;
+  }
+  Plan& pl = get_plan(d, K, Mg, par ? 2 : 1);
   hipStream_t st = stream ? (hipStream_t)stream : get_cuda_stream();
   for (int b0 = 0; b0 < d->batch; b0 += chunk)
   {
@@ -1139,6 +1216,15 @@ int dk_conv_backward_data_cfg(const DkConvDesc* d, const float* delta, const flo
     a.mode = 1;
     const int ci = (cfg_override >= 0 && cfg_override < g_ncfg) ? cfg_override : pick_cfg(Cg, a.N, d->groups);
     const TileCfg& c = g_cfgs[ci];
+    if (par)
+    {
+      a.mode = 2;
+      a.par_w2 = d->w / 2;
+      a.par_hw2 = (d->h / 2) * (d->w / 2);
+      a.par_count = nb * a.par_hw2;
+      a.par_ncls = (a.par_count + c.bn - 1) / c.bn * c.bn;
+      a.N = 4 * a.par_ncls;
+    }
     a.tiles_m = (Cg + c.bm - 1) / c.bm;
     a.tiles_n = (a.N + c.bn - 1) / c.bn;
     a.groups = d->groups;

@@ -21,8 +21,11 @@ int dk_conv_forward_cfg(const DkConvDesc* d, const float* x, const float* weight
 // wino_filters != nullptr: the transformed filters (dk_conv_wino_transform_weights) to use when `cfg` is the
 // Winograd configuration, instead of the registry entry of `weights` (training: the filters change every step)
 // dk_conv_backward_data with an explicit gather tile configuration (cfg < 0 or not a gather shape: heuristic)
+// wt_tapmajor != 0: `wt` comes from dk_transpose_weights_tapmajor and the layer takes the parity-class form
+// (dk_conv_dgrad_tapmajor): stride-2 layers visit only the taps whose parity matches the pixel class
 int dk_conv_backward_data_cfg(const DkConvDesc* d, const float* delta, const float* wt, float* prev_delta,
-    void* stream, int cfg);
+    void* stream, int cfg, int wt_tapmajor);
+bool dk_conv_dgrad_tapmajor(const DkConvDesc* d);
 // number of gather (implicit-GEMM) tile configurations: indices [0, n) of the configuration table
 int dk_conv_num_gather_configs();
 // dk_conv_backward_weights with an explicit tile shape (0..3: 128x128, 64x128, 128x64, 64x64 rows x taps; < 0: heuristic)

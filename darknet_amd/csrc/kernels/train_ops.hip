@@ -740,6 +740,20 @@ __global__ void transpose_w_kernel(const float* __restrict__ w, float* __restric
     wt[i] = w[((size_t)m * C + c) * ss + (flip ? ss - 1 - t : t)];
   }
 }
+// wt[c][t * M + m] = w[m][c][t]
+__global__ void transpose_w_tapmajor_kernel(const float* __restrict__ w, float* __restrict__ wt, int M, int C,
+    int ss, size_t total)
+{
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x)
+  {
+    const int m = (int)(i % M);
+    const size_t r = i / M;
+    const int t = (int)(r % ss);
+    const int c = (int)(r / ss);
+    wt[i] = w[((size_t)m * C + c) * ss + t];
+  }
+}
 }  // namespace
 
 // adam_update_gpu (src/blas_kernels.cu:99-134) in one pass, the reference's seven launches
@@ -798,6 +812,10 @@ extern "C" int dk_bn_forward_train(const float* raw, float* x_save, float* x_nor
   const size_t total = (size_t)batch * filters * spatial;
   if (total == 0)
     return 0;
+  // the same mish as the inference epilogue's default (one hardware exp and reciprocal instead of the libm
+  // chain, dk_device_math.h): with the libm form this pass was ALU-bound, not bandwidth-bound
+  if (activation == DK_MISH && dk_fast_mish_enabled())
+    activation |= DK_ACT_FAST;
   if (train)
   {
     hipStream_t st = S(stream);
@@ -1032,6 +1050,19 @@ extern "C" int dk_transpose_weights(const float* w, float* wt, int M, int C, int
     return 0;
   hipLaunchKernelGGL(transpose_w_kernel, dim3(grid_for(total)), dim3(256), 0, S(stream), w, wt, M,
       C, size * size, total, 0);
+  CHECK_HIP(hipPeekAtLastError());
+  return 0;
+}
+
+// wt[c][(t, m)] = w[m][c][t]: the contraction index of the data gradient ordered tap-major, for the parity-class
+// form of stride-2 layers (dk_conv_backward_data_tapmajor)
+extern "C" int dk_transpose_weights_tapmajor(const float* w, float* wt, int M, int C, int size, void* stream)
+{
+  const size_t total = (size_t)M * C * size * size;
+  if (total == 0)
+    return 0;
+  hipLaunchKernelGGL(transpose_w_tapmajor_kernel, dim3(grid_for(total)), dim3(256), 0, S(stream), w, wt, M, C,
+      size * size, total);
   CHECK_HIP(hipPeekAtLastError());
   return 0;
 }

@@ -12,6 +12,8 @@ the reference's own accumulation over `subdivisions` (one sub-batch per replica)
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 
 
@@ -58,7 +60,8 @@ class DataParallelTrainer:
         self.bucket = torch.zeros(n, dtype=torch.float32, device="cuda")
         L.DkAttachGradBucket(net.p, self.bucket.data_ptr())
         L.DkSetReplicas(net.p, ctx.world)
-        self.overlap = overlap
+        # DK_TRAIN_OVERLAP=0: the unsplit step (TrainNetworkDatum; with DK_TRAIN_TIMING=1 it prints host issue times)
+        self.overlap = overlap and os.environ.get("DK_TRAIN_OVERLAP", "1") != "0"
         # the library launches on its own HIP stream; torch collectives are ordered against it
         self.dk_stream = torch.cuda.ExternalStream(L.get_cuda_stream())
         offs = [L.DkGradBucketOffset(net.p, i) for i in range(net.n + 1)]

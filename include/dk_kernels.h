@@ -216,6 +216,14 @@ DK_API int dk_conv_backward_data(const DkConvDesc* d, const float* delta, const 
     float* prev_delta, void* stream);
 /* wt[g][c][(m,kh,kw)] = w[g][m][c][kh][kw]; call per group with M = n/groups, C = c/groups */
 DK_API int dk_transpose_weights(const float* w, float* wt, int M, int C, int size, void* stream);
+/* Stride-2 layers (both directions, even input dimensions, one group, filters a multiple of 32, size 2 or 3): the
+ * same data gradient with the pixels enumerated parity class by parity class and the contraction index tap-major
+ * (wt = dk_transpose_weights_tapmajor(weights): wt[c][t * n + m] = w[m][c][t]), so that only the taps whose parity
+ * matches a pixel are visited -- 9 instead of 36 tap-pixel pairs for a 3x3 layer.  Returns 1 when the layer does
+ * not take this form. */
+DK_API int dk_conv_backward_data_tapmajor(const DkConvDesc* d, const float* delta, const float* wt_tapmajor,
+    float* prev_delta, void* stream);
+DK_API int dk_transpose_weights_tapmajor(const float* w, float* wt, int M, int C, int size, void* stream);
 /* backward_maxpool_layer_kernel, src/maxpool_layer_kernels.cu:103-143 (scatter-add by index) */
 DK_API int dk_maxpool_backward(const float* delta, const int* indexes, size_t n,
     float* prev_delta, void* stream);

@@ -29,6 +29,8 @@ def bind(L):
         "dk_conv_backward_weights": [VP, VP, VP, VP, VP],
         "dk_conv_backward_data": [VP, VP, VP, VP, VP],
         "dk_transpose_weights": [VP, VP, i, i, i, VP],
+        "dk_transpose_weights_tapmajor": [VP, VP, i, i, i, VP],
+        "dk_conv_backward_data_tapmajor": [VP, VP, VP, VP, VP],
         "dk_maxpool_backward": [VP, VP, sz, VP, VP],
         "dk_route_backward": [VP, i, i, i, i, i, i, VP, VP],
         "dk_shortcut_backward": [VP, sz, VP, VP, VP],
@@ -81,6 +83,61 @@ def test_conv_backward_vs_oracle(gpu, case):
     assert G.dk_conv_backward_data(C.byref(d), dd.ptr, dt.ptr, dprev.ptr, None) == 0
     util.assert_close(ddw.numpy().reshape(wt.shape), ref_dw, "wgrad %s" % (case,))
     util.assert_close(dprev.numpy().reshape(x.shape), ref_prev, "dgrad %s" % (case,))
+
+
+PARITY_CASES = [
+    # batch, c, h, w, n, size (stride 2, pad size // 2): the parity-class data gradient of the downsampling layers
+    (2, 8, 14, 14, 32, 3),
+    (3, 16, 38, 38, 64, 3),      # several pixel tiles per class, class tails are padding
+    (1, 32, 76, 52, 96, 3),      # non-square, filters = 3 K tiles of 32
+    (2, 32, 304, 304, 64, 3),    # yolov4 layer 1's shape class at half size
+    (2, 24, 20, 20, 32, 2),      # 2x2 / stride 2 (one tap per class)
+]
+
+
+@pytest.mark.parametrize("case", PARITY_CASES)
+def test_conv_backward_data_parity_classes_vs_oracle(gpu, case):
+    """dk_conv_backward_data_tapmajor (stride-2 layers: pixels enumerated by parity class, tap-major contraction
+    index, only the matching taps visited) against the oracle's col2im data gradient, through every gather tile
+    shape, and against the masked-gather form of the same library."""
+    batch, c, h, w, n, size = case
+    stride, pad = 2, size // 2 if size == 3 else 0
+    L, G = O.lib(), bind(gpu.lib())
+    rng = np.random.default_rng(abs(hash(case)) & 0xFFFF)
+    oh, ow = (h + 2 * pad - size) // stride + 1, (w + 2 * pad - size) // stride + 1
+    x = rng.uniform(-1, 1, (batch, c, h, w)).astype(np.float32)
+    wt = (rng.uniform(-1, 1, (n, c, size, size)) * 0.2).astype(np.float32)
+    delta = rng.uniform(-1, 1, (batch, n, oh, ow)).astype(np.float32)
+    ref_dw, ref_prev = np.zeros_like(wt), np.full_like(x, 3.0)
+    ws = np.zeros(oh * ow * size * size * c + 1, np.float32)
+    L.orc_conv_backward(O.fptr(x), O.fptr(wt), O.fptr(delta), O.fptr(ref_dw), O.fptr(ref_prev), O.fptr(ws),
+                        batch, c, h, w, n, 1, size, stride, stride, 1, pad)
+    d = gpu.DkConvDesc(batch, c, h, w, n, 1, size, stride, stride, 1, pad, O.LINEAR)
+    dwt, dd = gpu.DeviceArray(wt), gpu.DeviceArray(delta)
+    dt = gpu.DeviceArray(n=wt.size)
+    assert G.dk_transpose_weights_tapmajor(dwt.ptr, dt.ptr, n, c, size, None) == 0
+    ncfg = gpu.lib().dk_conv_force_config(-1)
+    names = []
+    try:
+        for cfg in range(-1, ncfg):
+            if cfg >= 0 and not gpu.lib().dk_conv_config_name(cfg).decode()[0].isdigit():
+                break     # the gather shapes come first; direct / DMA / Winograd shapes do not take a data gradient
+            gpu.lib().dk_conv_force_config(cfg)
+            dprev = gpu.DeviceArray(np.full_like(x, 3.0))
+            assert G.dk_conv_backward_data_tapmajor(C.byref(d), dd.ptr, dt.ptr, dprev.ptr, None) == 0
+            util.assert_close(dprev.numpy().reshape(x.shape), ref_prev, "parity dgrad %s cfg %d" % (case, cfg))
+            names.append(cfg)
+    finally:
+        gpu.lib().dk_conv_force_config(-1)
+    assert len(names) >= 8
+    # and the masked form (every tap multiplied, zeros gathered) agrees to summation-order noise
+    dt2, dprev2 = gpu.DeviceArray(n=wt.size), gpu.DeviceArray(np.full_like(x, 3.0))
+    assert G.dk_transpose_weights(dwt.ptr, dt2.ptr, n, c, size, None) == 0
+    assert G.dk_conv_backward_data(C.byref(d), dd.ptr, dt2.ptr, dprev2.ptr, None) == 0
+    util.assert_close(dprev.numpy(), dprev2.numpy(), "parity vs masked dgrad %s" % (case,))
+    # a layer outside the form is refused, not mis-computed
+    d_odd = gpu.DkConvDesc(batch, c, h + 1, w, n, 1, size, stride, stride, 1, pad, O.LINEAR)
+    assert G.dk_conv_backward_data_tapmajor(C.byref(d_odd), dd.ptr, dt.ptr, dprev.ptr, None) == 1
 
 
 def test_batchnorm_forward_backward_vs_oracle(gpu):
