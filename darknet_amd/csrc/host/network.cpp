@@ -68,7 +68,8 @@ float GetCurrLr(Network* net)
   switch (net->policy)
   {
     case CONSTANT: return net->lr;
-    case STEP: return net->lr * (float)pow((double)net->scale, (double)(iter / net->step));
+    // pow(float, integer) promotes to double and the product with lr stays double until the return narrows it
+    case STEP: return (float)(net->lr * pow((double)net->scale, (double)(iter / net->step)));
     case STEPS:
     {
       float lr = net->lr;
@@ -80,9 +81,21 @@ float GetCurrLr(Network* net)
       }
       return lr;
     }
-    case EXP: return net->lr * (float)pow((double)net->gamma, (double)iter);
+    case EXP: return (float)(net->lr * pow((double)net->gamma, (double)iter));
     case POLY: return net->lr * powf(1 - (float)iter / net->max_iter, net->power);
     case SIG: return net->lr * (1. / (1. + exp(net->gamma * (iter - net->step))));
+    case SGDR:
+    {
+      // network.cpp:66-78: warm restarts; cos() on a float product promoted to double by M_PI
+      int last_iter = 0;
+      int cycle = net->sgdr_cycle;
+      while (last_iter + cycle < iter)
+      {
+        last_iter += cycle;
+        cycle *= net->sgdr_mult;
+      }
+      return net->lr_min + 0.5f * (net->lr - net->lr_min) * (1.0f + cos((float)(iter - last_iter) * M_PI / cycle));
+    }
     default: break;
   }
   fprintf(stderr, "GetCurrLr: policy %d is outside the supported hot path\n", (int)net->policy);

@@ -895,3 +895,4 @@ extern "C" LIB_API size_t DkGradBucketOffset(Network* net, int upto)
   return n;
 }
 extern "C" LIB_API void DkAdvanceIteration(Network* net) { net->curr_iter++; }
+extern "C" LIB_API void DkSetCurrIter(Network* net, long long iter) { net->curr_iter = iter; }

@@ -442,6 +442,7 @@ LIB_API void DkBackwardRange(Network* net, int hi, int lo);
 LIB_API float DkTrainFinish(Network* net);
 LIB_API size_t DkGradBucketOffset(Network* net, int upto_layer);
 LIB_API void DkAdvanceIteration(Network* net);
+LIB_API void DkSetCurrIter(Network* net, long long iter); /* net->curr_iter = iter (GetCurrLr / burn-in / stopbackward schedules) */
 /* D2H copy of a layer tensor: which = 6 delta, 7 weight_updates, 8 bias_updates,
  * 9 scale_updates, 1 weights, 2 biases, 3 scales, 4 rolling_mean, 5 rolling_variance,
  * 10 mean, 11 variance; returns the element count or -1 */

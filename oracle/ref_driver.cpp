@@ -185,6 +185,7 @@ void ref_update(Network* net)
 
 float ref_curr_lr(Network* net) { return GetCurrLr(net); }
 void ref_set_max_iter(Network* net, int max_iter) { net->max_iter = max_iter; }
+void ref_set_curr_iter(Network* net, long long iter) { net->curr_iter = iter; }
 void ref_save_weights(Network* net, const char* path);
 
 void ref_forward_train(Network* net, float* x, float* y)

@@ -258,3 +258,38 @@ def test_c_bucket_segments_equal_python_rule(dk):
             got = [tuple(out[4 * i:4 * i + 4]) for i in range(k)]
             assert got == [tuple(int(v) for v in s) for s in want], (name, nseg)
         L.DkNetworkDestroy(p)
+
+
+def test_learning_rate_schedules_vs_reference_golden(dk, tmp_path):
+    """GetCurrLr (network.cpp:32-84) for every deterministic policy -- burn-in ramp, step / steps boundaries, exp,
+    poly, sigmoid, SGDR warm restarts -- bit-exact against the real reference (tests/golden/lr_schedule.npz,
+    tools/make_golden.py lr)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_golden as MG
+    g = np.load(os.path.join(ROOT, "tests", "golden", "lr_schedule.npz"))
+    L = dk.lib()
+    L.ParseNetworkCfg.restype = C.c_bool
+    L.ParseNetworkCfg.argtypes = [C.c_void_p, C.c_char_p, C.c_bool]
+    L.DkNetworkCreate.restype = C.c_void_p
+    L.GetCurrLr.restype = C.c_float
+    L.GetCurrLr.argtypes = [C.c_void_p]
+    L.DkSetCurrIter.argtypes = [C.c_void_p, C.c_longlong]
+    L.DkSetMaxIter.argtypes = [C.c_void_p, C.c_int]
+    L.DkNetworkDestroy.argtypes = [C.c_void_p]
+    assert list(g["iters"]) == MG.LR_ITERS and int(g["max_iter"]) == MG.LR_MAX_ITER
+    for pol in MG.LR_POLICIES:
+        cfg = str(tmp_path / (pol + ".cfg"))
+        open(cfg, "w").write(MG.lr_cfg_text(pol))
+        p = L.DkNetworkCreate()
+        assert L.ParseNetworkCfg(p, cfg.encode(), False)
+        L.DkSetMaxIter(p, MG.LR_MAX_ITER)
+        got = []
+        for it in MG.LR_ITERS:
+            L.DkSetCurrIter(p, it)
+            got.append(L.GetCurrLr(p))
+        got = np.array(got, np.float32)
+        ref = g["lr_" + pol]
+        assert ref.max() > ref.min() or pol == "constant"
+        bad = np.nonzero(got.view(np.uint32) != ref.view(np.uint32))[0]
+        assert bad.size == 0, (pol, [(MG.LR_ITERS[i], float(got[i]), float(ref[i])) for i in bad[:5]])
+        L.DkNetworkDestroy(p)

@@ -714,8 +714,58 @@ def gen_map(name="yolov4-tiny", K=4):
     print(f"map_{name}.npz: thresh {thresh:.6f}, dets/image {[len(d) for d in dets_all]}, mAP {m:.6f}")
 
 
+LR_POLICIES = {
+    # name -> (the [net] lines that replace the tiny cfg's schedule, max_iter set through ref_set_max_iter)
+    "constant": "learning_rate=0.00261\nburn_in=1000\npower=4\npolicy=constant\n",
+    "step": "learning_rate=0.01\nburn_in=0\npolicy=step\nstep=400\nscale=.5\n",
+    "steps": "learning_rate=0.00261\nburn_in=1000\npolicy=steps\nsteps=.8,.9\nscales=.1,.1\n",
+    "exp": "learning_rate=0.01\nburn_in=100\npower=2\npolicy=exp\ngamma=.999\n",
+    "poly": "learning_rate=0.01\nburn_in=0\npower=4\npolicy=poly\n",
+    "sig": "learning_rate=0.01\nburn_in=0\npolicy=sigmoid\ngamma=.01\nstep=2500\n",
+    # (the reference dereferences steps= / scales= for sgdr too: a cfg without them crashes its parser)
+    "sgdr": "learning_rate=0.01\nlearning_rate_min=.0001\nburn_in=200\npolicy=sgdr\nsgdr_cycle=700\nsgdr_mult=2\nsteps=.5\nscales=1\n",
+}
+LR_MAX_ITER = 5000
+LR_ITERS = [0, 1, 2, 50, 99, 100, 101, 199, 200, 399, 400, 401, 699, 700, 701, 999, 1000, 1001, 1500, 2099, 2100, 2101,
+            2499, 2500, 2501, 3999, 4000, 4001, 4499, 4500, 4501, 4899, 4900, 4999, 5000]
+
+
+def lr_cfg_text(policy):
+    """yolov4-tiny with its learning-rate schedule lines replaced (shared with the test)."""
+    import re
+    txt = open(os.path.join(ROOT, "cfg", "yolov4-tiny.cfg")).read()
+    for key in ("learning_rate", "burn_in", "policy", "steps", "scales"):
+        txt = re.sub(r"(?m)^%s=.*\n" % key, "", txt, count=1)
+    txt = re.sub(r"batch=\d+", "batch=1", txt, count=1)
+    return txt.replace("[net]\n", "[net]\n" + LR_POLICIES[policy], 1)
+
+
+def gen_lr():
+    """GetCurrLr (network.cpp:32-84) of the real reference for every deterministic policy over burn-in, the step
+    boundaries and the warm restarts -> tests/golden/lr_schedule.npz."""
+    import tempfile
+    L = reflib.lib()
+    L.ref_set_curr_iter.argtypes = [C.c_void_p, C.c_longlong]
+    out = {"iters": np.array(LR_ITERS, np.int64), "max_iter": np.array(LR_MAX_ITER)}
+    with tempfile.TemporaryDirectory() as d:
+        for pol in LR_POLICIES:
+            cfg = os.path.join(d, pol + ".cfg")
+            open(cfg, "w").write(lr_cfg_text(pol))
+            net = reflib.RefNet(cfg, None, train=False)
+            L.ref_set_max_iter(net.p, LR_MAX_ITER)
+            v = []
+            for it in LR_ITERS:
+                L.ref_set_curr_iter(net.p, it)
+                v.append(L.ref_curr_lr(net.p))
+            out["lr_" + pol] = np.array(v, np.float32)
+            print(pol, v[:4], v[-3:])
+    np.savez_compressed(os.path.join(GOLD, "lr_schedule.npz"), **out)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "map":
+    if len(sys.argv) > 1 and sys.argv[1] == "lr":
+        gen_lr()
+    elif len(sys.argv) > 1 and sys.argv[1] == "map":
         gen_map()
     elif len(sys.argv) > 1 and sys.argv[1] == "gaussian":
         gen_gaussian()
