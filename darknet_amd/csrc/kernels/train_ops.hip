@@ -65,6 +65,34 @@ double* chan_scratch(int filters, hipStream_t st)
   return buf[dev];
 }
 
+// Scratch of the FUSED statistics paths (dk_bn_forward_train, dk_bn_act_backward): the consumer kernel
+// (bn_apply / bn_act_delta) finishes the statistics itself, so nobody is left to clear the sums; every call takes a
+// fresh slice of a per-device ring instead, and the ring is cleared as a whole when it wraps (one memset every few
+// steps instead of two tiny finalize launches per layer and pass: 217 launches per yolov4 step).
+double* chan_ring_take(size_t doubles, hipStream_t st)
+{
+  static double* buf[16];
+  static size_t off[16];
+  constexpr size_t CAP = (size_t)1 << 20;   // 8 MB
+  const int dev = cuda_get_device();
+  if (doubles > CAP)
+    return nullptr;
+  if (!buf[dev])
+  {
+    CHECK_HIP(hipMalloc((void**)&buf[dev], CAP * sizeof(double)));
+    CHECK_HIP(hipMemsetAsync(buf[dev], 0, CAP * sizeof(double), st));
+    off[dev] = 0;
+  }
+  if (off[dev] + doubles > CAP)
+  {
+    CHECK_HIP(hipMemsetAsync(buf[dev], 0, CAP * sizeof(double), st));
+    off[dev] = 0;
+  }
+  double* p = buf[dev] + off[dev];
+  off[dev] += doubles;
+  return p;
+}
+
 // split a channel's batch*spatial elements so that ~2048 workgroups exist in total
 inline void chan_split(int batch, int filters, int spatial, int* chunks, size_t* slice)
 {
@@ -170,7 +198,7 @@ __device__ __forceinline__ size_t chan_index(size_t t, int f, int filters, int s
 // Statistics in two stages so that low-channel layers still fill the chip: stage 1,
 // grid (chunks, filters): every workgroup reduces a slice of one channel to
 // {sum, sum of squares} in double and adds them to a per-channel scratch with fp64
-// atomics; stage 2, one thread per channel: mean = S/N, variance = (Q - S*S/N)/(N-1)
+// atomics; stage 2 (inside bn_apply_kernel since round 2b): mean = S/N, variance = (Q - S*S/N)/(N-1)
 // (the reference's N-1 denominator, src/blas.c:186; evaluated in double, so the
 // one-pass form loses nothing), rolling statistics .9/.1.
 __global__ void __launch_bounds__(RP) bn_partial_kernel(const float* __restrict__ x, int batch,
@@ -232,33 +260,6 @@ __global__ void __launch_bounds__(RP) bn_partial_kernel(const float* __restrict_
   block_reduce_atomic<2>(acc, scratch + 2 * f);
 }
 
-__global__ void bn_finalize_kernel(double* __restrict__ scratch, int batch, int filters,
-    int spatial, float* __restrict__ mean, float* __restrict__ variance,
-    float* __restrict__ rolling_mean, float* __restrict__ rolling_variance)
-{
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= filters)
-    return;
-  const double n = (double)batch * spatial;
-  const double s = scratch[2 * f], q = scratch[2 * f + 1];
-  scratch[2 * f] = 0;   // leave the scratch zeroed for the next reduction
-  scratch[2 * f + 1] = 0;
-  const float m = (float)(s / n);
-  double v = (q - s * s / n) / (n - 1);
-  if (v < 0)
-    v = 0;
-  const float var = (float)v;
-  mean[f] = m;
-  variance[f] = var;
-  // rolling = .9*rolling + .1*batch: scal_cpu then axpy_cpu, batchnorm_layer.cpp:221-224
-  float rm = rolling_mean[f] * .9f;
-  rm += .1f * m;
-  rolling_mean[f] = rm;
-  float rv = rolling_variance[f] * .9f;
-  rv += .1f * var;
-  rolling_variance[f] = rv;
-}
-
 // normalize_cpu (eps 1e-6) + scale_bias + add_bias + activation, one pass.
 // grid (batch*filters, chunks): one (image, channel) plane per blockIdx.x -> channel constants are
 // scalars, no per-element division, 16-byte accesses when the planes allow it.
@@ -273,15 +274,56 @@ __device__ __forceinline__ float bn_apply_one(float v, float m, float div, float
   return dk_activate(xn, act);
 }
 
+// sums != nullptr (train): the channel's {sum, sum of squares} from bn_partial_kernel; mean and variance are formed
+// here (mean = S/N, variance = (Q - S*S/N)/(N-1) in double), and the workgroup of image 0 / chunk 0 stores them and moves the
+// rolling statistics (mean / variance / rolling_* are outputs then)
 __global__ void bn_apply_kernel(const float* __restrict__ raw, float* __restrict__ x_save,
     float* __restrict__ x_norm, float* __restrict__ act_in, float* __restrict__ out,
-    const float* __restrict__ mean, const float* __restrict__ variance,
+    float* __restrict__ mean, float* __restrict__ variance,
     const float* __restrict__ scales, const float* __restrict__ biases, int filters, int spatial,
-    int act, int vec)
+    int act, int vec, const double* __restrict__ sums, int batch, float* __restrict__ rolling_mean,
+    float* __restrict__ rolling_variance)
 {
   const int plane = blockIdx.x;
   const int f = plane % filters;
-  const float m = mean[f], div = sqrtf(variance[f] + .000001f), sc = scales[f], bi = biases[f];
+  float m, var;
+  if (sums)
+  {
+    __shared__ float stat[2];
+    if (threadIdx.x == 0)
+    {
+      const double n = (double)batch * spatial;
+      const double s = sums[2 * f], q = sums[2 * f + 1];
+      const float mm = (float)(s / n);
+      double v = (q - s * s / n) / (n - 1);
+      if (v < 0)
+        v = 0;
+      const float vv = (float)v;
+      stat[0] = mm;
+      stat[1] = vv;
+      if (plane < filters && blockIdx.y == 0)
+      {
+        mean[f] = mm;
+        variance[f] = vv;
+        // rolling = .9*rolling + .1*batch: scal_cpu then axpy_cpu, batchnorm_layer.cpp:221-224
+        float rm = rolling_mean[f] * .9f;
+        rm += .1f * mm;
+        rolling_mean[f] = rm;
+        float rv = rolling_variance[f] * .9f;
+        rv += .1f * vv;
+        rolling_variance[f] = rv;
+      }
+    }
+    __syncthreads();
+    m = stat[0];
+    var = stat[1];
+  }
+  else
+  {
+    m = mean[f];
+    var = variance[f];
+  }
+  const float div = sqrtf(var + .000001f), sc = scales[f], bi = biases[f];
   const size_t base = (size_t)plane * spatial;
   if (vec)
   {
@@ -561,20 +603,42 @@ __global__ void __launch_bounds__(RP) bn_act_partial_kernel(const float* __restr
 // evaluated in double there (the literals promote it); here the three per-channel factors are formed once in
 // double and the element costs one fp64 multiply and one fma instead of two fp64 divisions -- the double
 // result differs by <= 2 ulp(double) before the final rounding to float.
+// sums: the channel's four sums from bn_act_partial_kernel; mean_delta / variance_delta are formed here exactly as
+// chan_finalize_kernel forms them, and the workgroup of image 0 / chunk 0 stores them and accumulates bias_updates /
+// scale_updates (all four are outputs).
 __global__ void bn_act_delta_kernel(float* __restrict__ delta, const float* __restrict__ x,
     const float* __restrict__ mean, const float* __restrict__ variance,
-    const float* __restrict__ mean_delta, const float* __restrict__ variance_delta,
+    float* __restrict__ mean_delta, float* __restrict__ variance_delta,
     const float* __restrict__ scales, const float* __restrict__ biases, int batch, int filters,
-    int spatial, int act, int vec)
+    int spatial, int act, int vec, const double* __restrict__ sums, float* __restrict__ bias_updates,
+    float* __restrict__ scale_updates)
 {
   const int plane = blockIdx.x;
   const int f = plane % filters;
   const int nb = spatial * batch;
   const float sc = scales[f], bi = biases[f], m = mean[f], var = variance[f];
   const float div = sqrtf(var + .000001f);
+  __shared__ float fin[2];
+  if (threadIdx.x == 0)
+  {
+    float md = (float)sums[4 * f + 2];
+    md *= (-1. / sqrtf(var + .00001f));
+    float vd = (float)sums[4 * f + 3];
+    vd *= -.5 * powf(var + .00001f, (float)(-3. / 2.));
+    fin[0] = md;
+    fin[1] = vd;
+    if (plane < filters && blockIdx.y == 0)
+    {
+      mean_delta[f] = md;
+      variance_delta[f] = vd;
+      bias_updates[f] += (float)sums[4 * f + 0];
+      scale_updates[f] += (float)sums[4 * f + 1];
+    }
+  }
+  __syncthreads();
   const double ka = 1. / (double)(sqrtf(var) + .00001f);
-  const double kb = (double)variance_delta[f] * 2. / (double)nb;
-  const double kc = (double)(mean_delta[f] / nb);
+  const double kb = (double)fin[1] * 2. / (double)nb;
+  const double kc = (double)(fin[0] / nb);
   float* dp = delta + (size_t)plane * spatial;
   const float* xp = x + (size_t)plane * spatial;
   auto one = [&](float xv, float dv) -> float {
@@ -816,16 +880,20 @@ extern "C" int dk_bn_forward_train(const float* raw, float* x_save, float* x_nor
   // chain, dk_device_math.h): with the libm form this pass was ALU-bound, not bandwidth-bound
   if (activation == DK_MISH && dk_fast_mish_enabled())
     activation |= DK_ACT_FAST;
+  hipStream_t st = S(stream);
+  double* sums = nullptr;
   if (train)
   {
-    hipStream_t st = S(stream);
-    double* scratch = chan_scratch(filters, st);
+    sums = chan_ring_take((size_t)2 * filters, st);
+    if (!sums)
+    {
+      fprintf(stderr, "dk_bn_forward_train: too many channels\n");
+      return 1;
+    }
     int cps, slice, ipw;
     plane_split2(batch, filters, spatial, &cps, &slice, &ipw);
     hipLaunchKernelGGL(bn_partial_kernel, dim3(cps * ((batch + ipw - 1) / ipw), filters), dim3(RP), 0, st, raw, batch,
-        filters, spatial, cps, slice, ipw, scratch);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((filters + 255) / 256), dim3(256), 0, st, scratch,
-        batch, filters, spatial, mean, variance, rolling_mean, rolling_variance);
+        filters, spatial, cps, slice, ipw, sums);
     CHECK_HIP(hipPeekAtLastError());
   }
   {
@@ -835,9 +903,9 @@ extern "C" int dk_bn_forward_train(const float* raw, float* x_save, float* x_nor
     const int vec = ((spatial & 3) == 0 && (al & 15) == 0) ? 1 : 0;
     int gx = (spatial + (vec ? 8191 : 1023)) / (vec ? 8192 : 1024);
     if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(batch * filters, gx), dim3(256), 0, S(stream), raw, xs, xn, act_in, out,
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(batch * filters, gx), dim3(256), 0, st, raw, xs, xn, act_in, out,
         train ? mean : rolling_mean, train ? variance : rolling_variance, scales, biases, filters, spatial,
-        activation, vec);
+        activation, vec, (const double*)sums, batch, rolling_mean, rolling_variance);
   }
   CHECK_HIP(hipPeekAtLastError());
   return 0;
@@ -913,19 +981,23 @@ extern "C" int dk_bn_act_backward(float* delta, const float* x, const float* mea
   hipStream_t st = S(stream);
   if (activation == DK_MISH && dk_fast_mish_enabled())
     activation |= DK_ACT_FAST;
-  double* scratch = chan_scratch(filters, st);
+  double* sums = chan_ring_take((size_t)4 * filters, st);
+  if (!sums)
+  {
+    fprintf(stderr, "dk_bn_act_backward: too many channels\n");
+    return 1;
+  }
   int cps, slice, ipw;
   plane_split2(batch, filters, spatial, &cps, &slice, &ipw);
   hipLaunchKernelGGL(bn_act_partial_kernel, dim3(cps * ((batch + ipw - 1) / ipw), filters), dim3(RP), 0, st, delta, x, mean,
-      variance, scales, biases, batch, filters, spatial, cps, slice, ipw, scratch, activation);
-  hipLaunchKernelGGL(chan_finalize_kernel, dim3((filters + 255) / 256), dim3(256), 0, st, scratch,
-      variance, filters, bias_updates, scale_updates, mean_delta, variance_delta, 1);
+      variance, scales, biases, batch, filters, spatial, cps, slice, ipw, sums, activation);
   const int vec = ((spatial & 3) == 0 && ((((uintptr_t)delta) | ((uintptr_t)x)) & 15) == 0) ? 1 : 0;
   // one 256-thread workgroup streams up to 8 K elements of its plane (two 16-byte positions in flight per thread)
   int gx = vec ? (spatial + 8191) / 8192 : (spatial + 1023) / 1024;
   if (gx > 64) gx = 64;
   hipLaunchKernelGGL(bn_act_delta_kernel, dim3(batch * filters, gx), dim3(256), 0, st, delta, x, mean,
-      variance, mean_delta, variance_delta, scales, biases, batch, filters, spatial, activation, vec);
+      variance, mean_delta, variance_delta, scales, biases, batch, filters, spatial, activation, vec,
+      (const double*)sums, bias_updates, scale_updates);
   CHECK_HIP(hipPeekAtLastError());
   return 0;
 }

@@ -217,6 +217,28 @@ def test_route_shortcut_upsample_yolo(gpu):
         util.assert_close(do.numpy().reshape(ref.shape), ref, "yolo decode sxy=%g" % sxy, rel=2e-6, atol_rms=1e-7)
 
 
+def test_add_bias_scale_bias_bitwise(gpu):
+    """dk_add_bias / dk_scale_bias (the plugin slots add_bias_gpu / scale_bias_gpu) == the oracle's add_bias /
+    scale_bias (convolutional_layer.cpp:916-944) bit for bit: one float add / multiply per element, incl. odd
+    plane sizes and a single-channel tensor."""
+    L, G = O.lib(), gpu.lib()
+    VP, i = C.c_void_p, C.c_int
+    for fn in (G.dk_add_bias, G.dk_scale_bias):
+        fn.argtypes = [VP, VP, i, i, i, VP]
+        fn.restype = i
+    rng = np.random.default_rng(11)
+    for batch, n, size in ((3, 7, 19 * 19), (2, 255, 13 * 13), (1, 1, 5), (4, 32, 76 * 76)):
+        x = rng.uniform(-2, 2, (batch, n, size)).astype(np.float32)
+        v = rng.uniform(-1.5, 1.5, n).astype(np.float32)
+        for gfn, ofn in ((G.dk_add_bias, L.orc_add_bias), (G.dk_scale_bias, L.orc_scale_bias)):
+            ref = x.copy()
+            ofn(O.fptr(ref), O.fptr(v), batch, n, size)
+            dx, dv = gpu.DeviceArray(x), gpu.DeviceArray(v)
+            assert gfn(dx.ptr, dv.ptr, batch, n, size, None) == 0
+            assert np.array_equal(dx.numpy().reshape(x.shape).view(np.uint32), ref.view(np.uint32)), (batch, n, size)
+    assert G.dk_add_bias(None, None, 0, 0, 0, None) == 0   # empty tensors are a no-op
+
+
 def test_activations_grid(gpu):
     """leaky / mish / logistic on a fixed grid incl. the +-20 softplus thresholds."""
     L, G = O.lib(), gpu.lib()
