@@ -68,3 +68,5 @@ bool dk_gpu_enabled();  // true when a HIP device is usable (cuda_get_device() >
 extern int g_dk_fusion, g_dk_graph, g_dk_autotune, g_dk_pull_heads;
 void DkPlanInference(Network* net);  // fusion pass + autotune + plan creation
 void DkInvalidateGraph(Network* net);
+void DkTrainPrepRun(Network* net);   // train.cpp: refresh the derived weight tensors (start of a train-mode forward)
+void DkFreeTrainPrep(Network* net);

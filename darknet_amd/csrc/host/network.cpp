@@ -537,8 +537,10 @@ void ForwardNetworkGpu(Network* net, NetworkState state)
 {
   state.workspace = net->workspace;
   hipStream_t st = get_cuda_stream();
-  if (state.train && net->delta_arena_gpu)
-    CHECK_HIP(hipMemsetAsync(net->delta_arena_gpu, 0, net->delta_arena_size * sizeof(float), st));
+  if (state.train)
+    DkTrainPrepRun(net);
+  if (state.train && net->delta_arena_gpu && net->delta_arena_zero)
+    CHECK_HIP(hipMemsetAsync(net->delta_arena_gpu, 0, net->delta_arena_zero * sizeof(float), st));   // see DkBuildDeltaArena
   for (int i = 0; i < net->n; ++i)
   {
     state.index = i;
@@ -1236,6 +1238,7 @@ void FreeNetwork(Network* net)
     cuda_free(net->workspace);
     cuda_free(net->wt_scratch_gpu);
     cuda_free(net->wino_scratch_gpu);
+    DkFreeTrainPrep(net);
     cuda_free(net->delta_arena_gpu);
     cuda_free(net->cand_gpu);
     cuda_free((float*)net->cand_counter_gpu);

@@ -88,6 +88,7 @@ void ResizeNetwork(Network* net, int w, int h)
     l->out_alias = nullptr;
     l->conv_cfg = -1;
     l->train_plan[0] = l->train_plan[1] = l->train_plan[2] = 0;
+    DkFreeTrainPrep(net);   // the kernel choices behind the derived-weights plan are void
     switch (l->type)
     {
       case CONVOLUTIONAL:

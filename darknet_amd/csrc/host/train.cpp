@@ -161,10 +161,10 @@ std::vector<int> forward_candidates(const DkConvDesc& d, bool wino_ok)
 // raw convolution y = w * x through configuration cfg; Winograd takes freshly transformed filters
 // from the network's scratch (stream-ordered: one scratch serves every layer)
 void train_conv(Network* net, const DkConvDesc& d, const float* x, const float* w, float* y, int cfg, hipStream_t st,
-    const char* what)
+    const char* what, const float* prepared_u = nullptr)
 {
-  const float* u = nullptr;
-  if (cfg >= 0 && dk_conv_config_is_wino(cfg))
+  const float* u = prepared_u;
+  if (!u && cfg >= 0 && dk_conv_config_is_wino(cfg))
   {
     if (dk_conv_wino_transform_weights(&d, w, net->wino_scratch_gpu, st))
       error(what);
@@ -245,6 +245,92 @@ extern "C" LIB_API int DkLayerTrainCfg(Network* net, int i, int kind)
   return (i >= 0 && i < net->n && kind >= 0 && kind < 3) ? net->layers[i].train_plan[kind] - 2 : -3;
 }
 
+// ---- derived weight tensors, one launch per step -------------------------------------------------------------
+// Once the first step has chosen every layer's kernels, the transposed weights of the data gradients and the
+// Winograd filters of both convolution passes are known tensors of the step: they are produced by ONE launch at
+// the start of the forward pass (weights only change in the update) into per-layer buffers, instead of one or two
+// small launches in front of every layer's kernels (~170 per yolov4 step).  DK_TRAIN_PREP=0 keeps the per-layer form.
+static bool same3_layer(const layer* l)
+{
+  return l->size == 3 && l->stride_x == 1 && l->stride_y == 1 && l->pad == 1 && l->dilation == 1 && l->groups == 1;
+}
+static bool plain1_layer(const layer* l)
+{
+  return l->size == 1 && l->stride_x == 1 && l->stride_y == 1 && l->pad == 0 && l->groups == 1;
+}
+
+void DkFreeTrainPrep(Network* net)
+{
+  if (net->train_prep)
+    dk_train_prep_destroy(net->train_prep);
+  net->train_prep = nullptr;
+  for (int i = 0; i < net->n; ++i)
+  {
+    layer* l = &net->layers[i];
+    if (l->type != CONVOLUTIONAL)
+      continue;
+    cuda_free(l->train_wt_gpu);
+    cuda_free(l->train_u_fwd_gpu);
+    cuda_free(l->train_u_dgrad_gpu);
+    l->train_wt_gpu = l->train_u_fwd_gpu = l->train_u_dgrad_gpu = nullptr;
+  }
+}
+
+static void build_train_prep(Network* net)
+{
+  std::vector<DkPrepTask> tasks;
+  for (int i = 0; i < net->n; ++i)
+  {
+    layer* l = &net->layers[i];
+    if (l->type != CONVOLUTIONAL)
+      continue;
+    const int Cg = l->c / l->groups, Mg = l->n / l->groups, ss = l->size * l->size;
+    if (l->train_plan[0] && dk_conv_config_is_wino(l->train_plan[0] - 2))
+    {
+      l->train_u_fwd_gpu = cuda_make_array(nullptr, (size_t)16 * l->n * l->c);
+      tasks.push_back({l->weights_gpu, l->train_u_fwd_gpu, l->n, l->c, 9, 3, 0});
+    }
+    if (i == 0 || !l->train_plan[1])
+      continue;   // no data gradient (first layer), or the layer never ran one (below a stopbackward)
+    const int cfg = l->train_plan[1] - 2;
+    if (same3_layer(l) && cfg >= 0 && dk_conv_config_is_wino(cfg))
+    {
+      l->train_u_dgrad_gpu = cuda_make_array(nullptr, (size_t)16 * l->n * l->c);
+      tasks.push_back({l->weights_gpu, l->train_u_dgrad_gpu, l->n, l->c, 9, 4, 0});
+      continue;
+    }
+    l->train_wt_gpu = cuda_make_array(nullptr, (size_t)l->nweights);
+    if (same3_layer(l))
+      tasks.push_back({l->weights_gpu, l->train_wt_gpu, Mg, Cg, ss, 1, 0});
+    else if (plain1_layer(l))
+      tasks.push_back({l->weights_gpu, l->train_wt_gpu, Mg, Cg, ss, 0, 0});
+    else
+    {
+      DkConvDesc d = conv_desc_of(l, (int)LINEAR);
+      if (dk_conv_dgrad_tapmajor(&d))
+        tasks.push_back({l->weights_gpu, l->train_wt_gpu, Mg, Cg, ss, 2, 0});
+      else
+        for (int g = 0; g < l->groups; ++g)
+          tasks.push_back({l->weights_gpu + (size_t)g * l->nweights / l->groups, l->train_wt_gpu + (size_t)g * l->nweights / l->groups,
+              Mg, Cg, ss, 0, 0});
+    }
+  }
+  net->train_prep = dk_train_prep_create((int)tasks.size(), tasks.data());
+}
+
+void DkTrainPrepRun(Network* net)
+{
+  static const bool on = !(getenv("DK_TRAIN_PREP") && !atoi(getenv("DK_TRAIN_PREP")));
+  if (!on || !net->train)
+    return;
+  // the first step chooses the kernels (which tensors are needed follows from the choice)
+  if (!net->train_prep && net->train_steps >= 1 && train_tune_on())
+    build_train_prep(net);
+  ++net->train_steps;
+  if (net->train_prep && dk_train_prep_run(net->train_prep, get_cuda_stream()))
+    error("derived-weights launch failed");
+}
+
 // conv with un-folded batch norm: raw GEMM -> x_gpu, statistics, normalise+scale+bias+act
 void ForwardConvTrainGpu(layer* l, NetworkState state)
 {
@@ -270,7 +356,8 @@ void ForwardConvTrainGpu(layer* l, NetworkState state)
     cfg = train_choice(l, 0, d, forward_candidates(d, wino_ok), dk_conv_pick_config(&d),
         [&](int c) { train_conv(net, d, x, l->weights_gpu, raw, c, st, "ForwardConvolutionalLayerGpu (train, timing) failed"); }, st);
     LayerScope ls(l, state.index, 0, cfg, st);
-    train_conv(net, d, x, l->weights_gpu, raw, cfg, st, "ForwardConvolutionalLayerGpu (train) failed");
+    train_conv(net, d, x, l->weights_gpu, raw, cfg, st, "ForwardConvolutionalLayerGpu (train) failed",
+        (net->train_prep && cfg >= 0 && dk_conv_config_is_wino(cfg)) ? l->train_u_fwd_gpu : nullptr);
   }
   else if (dk_conv_forward_cfg(&d, state.input, l->weights_gpu, nullptr, raw, nullptr, nullptr, st, -1))
     error("ForwardConvolutionalLayerGpu (train) failed");
@@ -321,16 +408,20 @@ void BackwardConvolutionalLayerGpu(layer* l, NetworkState state)
   {
     const int Cg = l->c / l->groups, Mg = l->n / l->groups;
     float* wt = net->wt_scratch_gpu;
-    const bool same3 = l->size == 3 && l->stride_x == 1 && l->stride_y == 1 && l->pad == 1 && l->dilation == 1 &&
-                       l->groups == 1;
-    const bool plain1 = l->size == 1 && l->stride_x == 1 && l->stride_y == 1 && l->pad == 0 && l->groups == 1;
+    const bool same3 = same3_layer(l), plain1 = plain1_layer(l);
+    // derived tensors already made by this step's DkTrainPrepRun?
+    const bool prepared = net->train_prep && l->train_plan[1] && (l->train_wt_gpu || l->train_u_dgrad_gpu);
+    if (prepared)
+      wt = l->train_wt_gpu;
     if (same3 || plain1)
     {
       // stride-1 "same" 3x3: the data gradient IS a 3x3/s1/p1 convolution of delta with the transposed,
       // 180-degree-rotated filters; 1x1/s1: a 1x1 convolution with the transposed matrix -> the forward
       // kernels (patch-in-LDS / Winograd / LDS-DMA GEMM where they apply).  Overwrites prev_delta like the
       // gather path.
-      if (same3)
+      if (prepared)
+        ;
+      else if (same3)
         dk_transpose_weights_flip(l->weights_gpu, wt, Mg, Cg, 3, st);
       else
         dk_transpose_weights(l->weights_gpu, wt, Mg, Cg, 1, st);
@@ -340,12 +431,16 @@ void BackwardConvolutionalLayerGpu(layer* l, NetworkState state)
       const int cfg = train_choice(l, 1, dd, forward_candidates(dd, wino_ok), dk_conv_pick_config(&dd),
           [&](int c) { train_conv(net, dd, l->delta_gpu, wt, state.delta, c, st, "data gradient (as convolution, timing) failed"); }, st);
       LayerScope ls(l, state.index, 1, cfg, st);
-      train_conv(net, dd, l->delta_gpu, wt, state.delta, cfg, st, "data gradient (as convolution) failed");
+      // (with prepared Winograd filters `wt` is NULL and never read: the kernel takes the filters alone)
+      train_conv(net, dd, l->delta_gpu, prepared && !wt ? l->weights_gpu : wt, state.delta, cfg, st,
+          "data gradient (as convolution) failed", prepared ? l->train_u_dgrad_gpu : nullptr);
       return;
     }
     // stride-2 layers: parity-class form (tap-major contraction index, only the matching taps are visited)
     const int tapmajor = dk_conv_dgrad_tapmajor(&d) ? 1 : 0;
-    if (tapmajor)
+    if (prepared)
+      ;
+    else if (tapmajor)
       dk_transpose_weights_tapmajor(l->weights_gpu, wt, Mg, Cg, l->size, st);
     else
       for (int g = 0; g < l->groups; ++g)

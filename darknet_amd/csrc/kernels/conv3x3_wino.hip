@@ -544,15 +544,10 @@ __global__ void __launch_bounds__(512) conv3x3_wino_f32(const ConvArgs p)
     emit(std::integral_constant<int, -1>());
 }
 
-// U = G g G^T of every (filter, channel), written in the kernel's slab order
-// [filter tile][stage][xi][sub-block][half][32 rows][4 floats]
-__global__ void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int M, int C)
+// U = G g G^T of one (filter m, channel c) with taps g[9], written in the kernel's slab order
+// [filter tile][stage][xi][sub-block][half][32 rows][4 floats]; C = channels of the convolution
+__device__ __forceinline__ void wino_transform_one(const float (&g)[9], float* __restrict__ U, int m, int c, int C)
 {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= M * C)
-    return;
-  const int m = idx / C, c = idx - m * C;
-  const float* g = w + (size_t)idx * 9;
   float gg[4][3];
 #pragma unroll
   for (int j = 0; j < 3; ++j)
@@ -577,6 +572,86 @@ __global__ void wino_weights_kernel(const float* __restrict__ w, float* __restri
     slab[img_off(i * 4 + 1, mm >> 5, mm & 31, c % WCK)] = u1;
     slab[img_off(i * 4 + 2, mm >> 5, mm & 31, c % WCK)] = u2;
     slab[img_off(i * 4 + 3, mm >> 5, mm & 31, c % WCK)] = u3;
+  }
+}
+
+__global__ void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int M, int C)
+{
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * C)
+    return;
+  const int m = idx / C, c = idx - m * C;
+  float g[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) g[t] = w[(size_t)idx * 9 + t];
+  wino_transform_one(g, U, m, c, C);
+}
+
+// Every derived weight tensor of a training step in ONE launch (dk_train_prep_*): per task a block range;
+// kinds 0-2 produce the data gradient's transposed weights (plain, rotated by 180 degrees, tap-major), kinds 3-4
+// the Winograd filters of the forward convolution and of the data gradient (the latter straight from w: the
+// convolution that computes the data gradient has filters w'[c][m][t] = w[m][c][8 - t]).
+__global__ void __launch_bounds__(256) train_prep_kernel(const DkPrepTask* __restrict__ tasks, int ntasks)
+{
+  // the task whose block range holds this block (ranges ascend)
+  int lo = 0, hi = ntasks - 1;
+  while (lo < hi)
+  {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tasks[mid].first_block <= (int)blockIdx.x)
+      lo = mid;
+    else
+      hi = mid - 1;
+  }
+  const DkPrepTask t = tasks[lo];
+  const int lb = (int)blockIdx.x - t.first_block;
+  const int M = t.M, C = t.C, ss = t.ss;
+  if (t.kind <= 2)
+  {
+    const size_t total = (size_t)M * C * ss;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+    {
+      const size_t i = ((size_t)lb * 4 + k) * 256 + threadIdx.x;
+      if (i >= total)
+        break;
+      size_t src;
+      if (t.kind == 2)
+      {
+        const int m = (int)(i % M);
+        const size_t r = i / M;
+        const int tap = (int)(r % ss), c = (int)(r / ss);
+        src = ((size_t)m * C + c) * ss + tap;
+      }
+      else
+      {
+        const int tap = (int)(i % ss);
+        const size_t r = i / ss;
+        const int m = (int)(r % M), c = (int)(r / M);
+        src = ((size_t)m * C + c) * ss + (t.kind == 1 ? ss - 1 - tap : tap);
+      }
+      t.dst[i] = t.w[src];
+    }
+    return;
+  }
+  const int idx = lb * 256 + (int)threadIdx.x;
+  if (idx >= M * C)
+    return;
+  float g[9];
+  if (t.kind == 3)
+  {
+    const int m = idx / C, c = idx - m * C;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) g[k] = t.w[(size_t)idx * 9 + k];
+    wino_transform_one(g, t.dst, m, c, C);
+  }
+  else
+  {
+    // filter c of the data-gradient convolution, its channel m: idx = c * M + m
+    const int c = idx / M, m = idx - c * M;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) g[k] = t.w[((size_t)m * C + c) * 9 + (8 - k)];
+    wino_transform_one(g, t.dst, c, m, M);
   }
 }
 
@@ -742,4 +817,51 @@ extern "C" void dk_conv_wino_register(const float* weights, const float* U)
     g_reg[weights] = U;
   else
     g_reg.erase(weights);
+}
+
+// ---- derived weights of a training step in one launch (host/train.cpp) ----------------------------------------
+struct DkTrainPrep
+{
+  DkPrepTask* tasks = nullptr;
+  int ntasks = 0, nblocks = 0;
+};
+
+void* dk_train_prep_create(int ntasks, DkPrepTask* host_tasks)
+{
+  if (ntasks <= 0)
+    return nullptr;
+  DkTrainPrep* p = new DkTrainPrep();
+  int nb = 0;
+  for (int i = 0; i < ntasks; ++i)
+  {
+    DkPrepTask& t = host_tasks[i];
+    t.first_block = nb;
+    const size_t items = t.kind <= 2 ? ((size_t)t.M * t.C * t.ss + 1023) / 1024 : ((size_t)t.M * t.C + 255) / 256;
+    nb += (int)items;
+  }
+  p->ntasks = ntasks;
+  p->nblocks = nb;
+  CHECK_HIP(hipMalloc((void**)&p->tasks, sizeof(DkPrepTask) * ntasks));
+  CHECK_HIP(hipMemcpy(p->tasks, host_tasks, sizeof(DkPrepTask) * ntasks, hipMemcpyHostToDevice));
+  return p;
+}
+
+void dk_train_prep_destroy(void* plan)
+{
+  DkTrainPrep* p = (DkTrainPrep*)plan;
+  if (!p)
+    return;
+  (void)hipFree(p->tasks);
+  delete p;
+}
+
+int dk_train_prep_run(void* plan, void* stream)
+{
+  DkTrainPrep* p = (DkTrainPrep*)plan;
+  if (!p || !p->nblocks)
+    return 0;
+  hipLaunchKernelGGL(train_prep_kernel, dim3((unsigned)p->nblocks), dim3(256), 0,
+      stream ? (hipStream_t)stream : get_cuda_stream(), p->tasks, p->ntasks);
+  CHECK_HIP(hipPeekAtLastError());
+  return 0;
 }

@@ -1034,6 +1034,12 @@ int dk_conv_forward_cfg(const DkConvDesc* d, const float* x, const float* weight
         continue;
       }
       dk_prof_end(ps, st, dk_prof_named_slot("conv3x3_wino_f32 (geometry does not fit: fell back)"), 0.0);
+      if (wino_filters)
+      {
+        // the caller handed over transformed filters only: `weights` need not be the plain filters of this convolution
+        fprintf(stderr, "dk_conv_forward: explicit Winograd filters, but the launch geometry does not fit\n");
+        return 1;
+      }
       want = -1;   // raw-patch geometry does not fit the compiled load counts: take the direct kernel
     }
     if (want < 0)

@@ -77,3 +77,18 @@ void* dk_sgd_plan_create(int ntensors, float* const* weights, float* const* upda
     const float* lr_scales, const int* use_decay);
 void dk_sgd_plan_destroy(void* plan);
 int dk_sgd_update_multi(void* plan, int batch, float learning_rate, float momentum, float decay, void* stream);
+
+// ---- derived weight tensors of a training step, all in one launch (conv3x3_wino.hip) -------------------------
+// kind 0: dst[c][m][t] = w[m][c][t]; 1: dst[c][m][t] = w[m][c][ss-1-t]; 2: dst[c][t*M + m] = w[m][c][t];
+// 3: dst = Winograd filters of w (M filters, C channels); 4: dst = Winograd filters of the data-gradient
+// convolution (C filters, M channels, taps rotated).  M / C are the LAYER's filters / channels per group.
+struct DkPrepTask
+{
+  const float* w;
+  float* dst;
+  int M, C, ss, kind;
+  int first_block;   // set by dk_train_prep_create
+};
+void* dk_train_prep_create(int ntasks, DkPrepTask* host_tasks);
+void dk_train_prep_destroy(void* plan);
+int dk_train_prep_run(void* plan, void* stream);

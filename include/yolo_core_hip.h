@@ -243,6 +243,10 @@ struct layer
   float* weights_wino_gpu; /* filters transformed for conv3x3_wino_f32 (inference plan, DkSetWinograd), or NULL */
   int train_plan[3];     /* train step: forward / data-gradient / weight-gradient tile configuration + 2, timed on the
                           * layer's own tensors at the first step (1 = the heuristic, 0 = not chosen yet) */
+  /* train: derived weight tensors refreshed by ONE launch per step (DkTrainPrepRun) instead of a transpose /
+   * filter-transform launch per layer and pass: the data gradient's transposed weights, the Winograd filters of
+   * the forward convolution and of the data-gradient convolution; NULL = made on the fly */
+  float *train_wt_gpu, *train_u_fwd_gpu, *train_u_dgrad_gpu;
   int delta_in_arena;    /* delta_gpu points into net->delta_arena_gpu (not freed per layer) */
   int buffers_aliased;   /* [dropout]: output_gpu / delta_gpu are the previous layer's (not freed here) */
   float* out_view;       /* producer: where the output really goes (a channel slice), or NULL */
@@ -297,6 +301,8 @@ struct Network
   int graph_batch;
   float* wt_scratch_gpu; /* transposed weights of the layer whose data gradient is running */
   float* wino_scratch_gpu; /* train: Winograd-transformed filters of the layer that is running (they change every step) */
+  void* train_prep;      /* train: plan of the per-step derived-weights launch (built after the first step's kernel choices) */
+  int train_steps;       /* train: forward passes run in train mode */
   /* device-side detection extraction and u8 input staging (see DkSetPullHeads, DkNetworkPredictU8) */
   float* cand_gpu;       /* candidate records written by dk_yolo_compact */
   int* cand_counter_gpu;
@@ -322,6 +328,7 @@ struct Network
   int u8_src_w, u8_src_h, u8_swap_rb; /* staged frames at another resolution (DkNetworkStageFrames): 0 = network size */
   float* delta_arena_gpu; /* train: every layer's delta_gpu lives in this one allocation (one memset per step) */
   size_t delta_arena_size;
+  size_t delta_arena_zero; /* leading floats of the arena that must start a step at zero (the rest is overwritten before it is read) */
   float* grad_bucket;    /* caller-owned contiguous gradient bucket (DkAttachGradBucket), or NULL */
   int grad_replicas;     /* data-parallel replicas whose buckets are summed before the update (DkSetReplicas) */
   void* dp;              /* data-parallel state of this replica (TrainNetworks: bucket, RCCL communicator, streams) */
