@@ -70,3 +70,5 @@ void DkPlanInference(Network* net);  // fusion pass + autotune + plan creation
 void DkInvalidateGraph(Network* net);
 void DkTrainPrepRun(Network* net);   // train.cpp: refresh the derived weight tensors (start of a train-mode forward)
 void DkFreeTrainPrep(Network* net);
+void DkJoinWgradStream(Network* net);   // train.cpp: main stream waits for the weight gradients on the second stream
+void DkFreeWgradStream(Network* net);

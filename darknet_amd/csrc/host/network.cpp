@@ -1239,6 +1239,7 @@ void FreeNetwork(Network* net)
     cuda_free(net->wt_scratch_gpu);
     cuda_free(net->wino_scratch_gpu);
     DkFreeTrainPrep(net);
+    DkFreeWgradStream(net);
     cuda_free(net->delta_arena_gpu);
     cuda_free(net->cand_gpu);
     cuda_free((float*)net->cand_counter_gpu);

@@ -318,17 +318,86 @@ static void build_train_prep(Network* net)
   net->train_prep = dk_train_prep_create((int)tasks.size(), tasks.data());
 }
 
+static int g_train_prep = -1;   // -1: DK_TRAIN_PREP (default on)
+extern "C" LIB_API void DkSetTrainPrep(int on) { g_train_prep = on; }
+
 void DkTrainPrepRun(Network* net)
 {
-  static const bool on = !(getenv("DK_TRAIN_PREP") && !atoi(getenv("DK_TRAIN_PREP")));
-  if (!on || !net->train)
+  static const bool env_on = !(getenv("DK_TRAIN_PREP") && !atoi(getenv("DK_TRAIN_PREP")));
+  const bool on = g_train_prep >= 0 ? g_train_prep != 0 : env_on;
+  if (!net->train)
     return;
+  if (!on)
+  {
+    if (net->train_prep)
+      DkFreeTrainPrep(net);   // switched off: back to the per-layer launches
+    ++net->train_steps;
+    return;
+  }
   // the first step chooses the kernels (which tensors are needed follows from the choice)
   if (!net->train_prep && net->train_steps >= 1 && train_tune_on())
     build_train_prep(net);
   ++net->train_steps;
   if (net->train_prep && dk_train_prep_run(net->train_prep, get_cuda_stream()))
     error("derived-weights launch failed");
+}
+
+// ---- second stream for the weight gradients (DK_TRAIN_STREAMS=0: everything on the main stream) ----------------
+struct WgradStream
+{
+  hipStream_t s = nullptr;
+  hipEvent_t ready = nullptr, done = nullptr;   // main -> second (inputs final), second -> main (join)
+  bool pending = false;
+};
+
+static bool train_streams_on()
+{
+  static const bool on = !(getenv("DK_TRAIN_STREAMS") && !atoi(getenv("DK_TRAIN_STREAMS")));
+  return on;
+}
+
+// the stream this layer's weight gradient goes to, ordered behind everything enqueued on `st` so far
+static hipStream_t wgrad_stream_of(Network* net, bool tuned_before, hipStream_t st)
+{
+  if (!train_streams_on() || !tuned_before)
+    return st;
+  WgradStream* w = (WgradStream*)net->wgrad_stream;
+  if (!w)
+  {
+    w = new WgradStream();
+    CHECK_HIP(hipStreamCreateWithFlags(&w->s, hipStreamNonBlocking));
+    CHECK_HIP(hipEventCreateWithFlags(&w->ready, hipEventDisableTiming));
+    CHECK_HIP(hipEventCreateWithFlags(&w->done, hipEventDisableTiming));
+    net->wgrad_stream = w;
+  }
+  CHECK_HIP(hipEventRecord(w->ready, st));
+  CHECK_HIP(hipStreamWaitEvent(w->s, w->ready, 0));
+  w->pending = true;
+  return w->s;
+}
+
+// the main stream waits for every weight gradient enqueued so far
+void DkJoinWgradStream(Network* net)
+{
+  WgradStream* w = (WgradStream*)net->wgrad_stream;
+  if (!w || !w->pending)
+    return;
+  CHECK_HIP(hipEventRecord(w->done, w->s));
+  CHECK_HIP(hipStreamWaitEvent(get_cuda_stream(), w->done, 0));
+  w->pending = false;
+}
+
+void DkFreeWgradStream(Network* net)
+{
+  WgradStream* w = (WgradStream*)net->wgrad_stream;
+  if (!w)
+    return;
+  (void)hipStreamSynchronize(w->s);
+  (void)hipEventDestroy(w->ready);
+  (void)hipEventDestroy(w->done);
+  (void)hipStreamDestroy(w->s);
+  delete w;
+  net->wgrad_stream = nullptr;
 }
 
 // conv with un-folded batch norm: raw GEMM -> x_gpu, statistics, normalise+scale+bias+act
@@ -395,13 +464,22 @@ void BackwardConvolutionalLayerGpu(layer* l, NetworkState state)
     // weight gradient: tile shapes 0..3 (conv_wgrad.hip) or its own heuristic (-1); the timing runs
     // accumulate into the transpose scratch (nweights floats fit: it is sized for the largest layer)
     float* scratch_dw = net->wt_scratch_gpu;
+    // (kernel timing of this layer -- first step -- happens on the main stream with the second one drained)
+    const bool tuned_before = l->train_plan[2] != 0 && (!state.delta || l->train_plan[1] != 0);
+    if (!tuned_before)
+      DkJoinWgradStream(net);
     const int wcfg = train_choice(l, 2, d, scratch_dw ? std::vector<int>{-1, 0, 1, 2, 3} : std::vector<int>{-1}, -1,
         [&](int c) {
           if (dk_conv_backward_weights_cfg(&d, state.input, l->delta_gpu, scratch_dw, st, c))
             error("weight gradient (timing) failed");
         }, st);
-    LayerScope ls(l, state.index, 2, wcfg, st);
-    if (dk_conv_backward_weights_cfg(&d, state.input, l->delta_gpu, l->weight_updates_gpu, st, wcfg))
+    // Nothing in the backward sweep reads weight_updates, so the weight gradient leaves the critical path: it is
+    // launched on the network's second stream behind an event (its inputs -- this layer's delta, the previous
+    // layer's output -- are final), and the data gradient, the next layers' batch-norm passes (bandwidth-bound)
+    // and their small-grid GEMMs share the chip with it.  backward_range joins the stream when it returns.
+    hipStream_t sw = wgrad_stream_of(net, tuned_before, st);
+    LayerScope ls(l, state.index, 2, wcfg, sw);
+    if (dk_conv_backward_weights_cfg(&d, state.input, l->delta_gpu, l->weight_updates_gpu, sw, wcfg))
       error("weight gradient failed");
   }
   if (state.delta)
@@ -685,6 +763,7 @@ static void backward_range(Network* net, NetworkState state, int hi, int lo)
     if (l->backward_gpu)
       l->backward_gpu(l, state);
   }
+  DkJoinWgradStream(net);   // the caller's next step (all-reduce of this segment, update) reads weight_updates
 }
 
 void BackwardNetworkGpu(Network* net, NetworkState state)

@@ -301,6 +301,7 @@ struct Network
   int graph_batch;
   float* wt_scratch_gpu; /* transposed weights of the layer whose data gradient is running */
   float* wino_scratch_gpu; /* train: Winograd-transformed filters of the layer that is running (they change every step) */
+  void* wgrad_stream;    /* train: second HIP stream + events the weight gradients run on (off the backward critical path) */
   void* train_prep;      /* train: plan of the per-step derived-weights launch (built after the first step's kernel choices) */
   int train_steps;       /* train: forward passes run in train mode */
   /* device-side detection extraction and u8 input staging (see DkSetPullHeads, DkNetworkPredictU8) */
@@ -449,6 +450,7 @@ LIB_API void DkBackwardRange(Network* net, int hi, int lo);
 LIB_API float DkTrainFinish(Network* net);
 LIB_API size_t DkGradBucketOffset(Network* net, int upto_layer);
 LIB_API void DkAdvanceIteration(Network* net);
+LIB_API void DkSetTrainPrep(int on); /* 1 (default): derived weight tensors of a train step in one launch; 0: per layer */
 LIB_API void DkSetCurrIter(Network* net, long long iter); /* net->curr_iter = iter (GetCurrLr / burn-in / stopbackward schedules) */
 /* D2H copy of a layer tensor: which = 6 delta, 7 weight_updates, 8 bias_updates,
  * 9 scale_updates, 1 weights, 2 biases, 3 scales, 4 rolling_mean, 5 rolling_variance,

@@ -527,6 +527,51 @@ def test_split_train_step_equals_train_network_datum(gpu, tmp_path):
     a.close(); b.close()
 
 
+def test_derived_weights_launch_equals_per_layer_form(gpu, tmp_path):
+    """From the second step on, the transposed / rotated / tap-major data-gradient weights and the Winograd filters
+    come from ONE launch per step (DkTrainPrepRun) into per-layer buffers.  Three steps with that form and three with
+    the per-layer launches (DkSetTrainPrep(0)) must train the same network: the tensors are copies / the same
+    transform of the same weights, so the only difference left is the float-atomic order of the weight gradient."""
+    g, cfg, wpath, x = train_fixture(tmp_path)
+    L = gpu.lib()
+    for fn, at, rt in (("TrainNetworkDatum", [VP, VP, VP], C.c_float), ("UpdateNetworkGpu", [VP], None),
+                       ("DkAdvanceIteration", [VP], None), ("DkSetMaxIter", [VP, C.c_int], None),
+                       ("DkSetTrainPrep", [C.c_int], None), ("DkLayerTrainCfg", [VP, C.c_int, C.c_int], C.c_int),
+                       ("DkLayerPull", [VP, C.c_int, C.c_int, VP, C.c_size_t], C.c_long)):
+        getattr(L, fn).argtypes = at
+        getattr(L, fn).restype = rt
+    truth = np.ascontiguousarray(g["truth"])
+    xin = np.ascontiguousarray(x)
+    res = {}
+    try:
+        for mode in (1, 0):
+            L.DkSetTrainPrep(mode)
+            net = netutil.DkNet(gpu, cfg, wpath, train=True)
+            L.DkSetMaxIter(net.p, 1000)
+            costs = []
+            for _ in range(3):
+                costs.append(L.TrainNetworkDatum(net.p, xin.ctypes.data, truth.ctypes.data))
+                L.DkAdvanceIteration(net.p)
+                L.UpdateNetworkGpu(net.p)
+            convs = [i for i in range(net.n) if net.info(i)["type"] == O.CONVOLUTIONAL]
+            w = {}
+            for i in convs:
+                n = net.info(i)["nweights"]
+                out = np.empty(n, np.float32)
+                assert L.DkLayerPull(net.p, i, 1, out.ctypes.data, n) == n
+                w[i] = out
+            kinds = {(L.DkLayerTrainCfg(net.p, i, 0), L.DkLayerTrainCfg(net.p, i, 1)) for i in convs}
+            res[mode] = (costs, w, kinds)
+            net.close()
+    finally:
+        L.DkSetTrainPrep(-1)
+    (ca, wa, ka), (cb, wb, kb) = res[1], res[0]
+    assert ka == kb and len(ka) >= 3      # same kernel choices (process-wide timing cache), several kinds of them
+    assert np.allclose(ca, cb, rtol=1e-4), (ca, cb)
+    for i in wa:
+        util.assert_close(wa[i], wb[i], "weights of conv %d after three steps" % i, rel=1e-4, atol_rms=1e-5)
+
+
 def test_stopbackward_split_step_equals_unsplit(gpu, tmp_path):
     """`stopbackward=1` (network_kernels.cu:140-143 ends the backward sweep for good): the split step must
     not resume the sweep in the next DkBackwardRange segment -- gradients below the stop layer stay exactly what

@@ -30,7 +30,7 @@ def main():
         print("| `%s` | %.1f | %.1f | %.3f | %.1f %% |" % (n, cnt[n] / steps, 1e3 * t / cnt[n], t / steps, 100 * t / steps / busy))
     groups = [("weight gradient", "conv_wgrad|wgrad_fold"), ("forward / data-gradient convolutions", "conv_igemm|conv3x3|conv1x1"),
               ("batch norm (+ activation) kernels", "bn_|chan_"), ("copies / fills", "copyBuffer|fillBuffer"),
-              ("weight transposes / Winograd filter transforms", "transpose_w|wino_weights")]
+              ("weight transposes / Winograd filter transforms", "transpose_w|wino_weights|train_prep")]
     print("\n| group | ms/step |\n|---|---|")
     rest = busy
     for g, pat in groups:
