@@ -652,7 +652,7 @@ static double now_ms()
 struct LossTask
 {
   std::future<float> fut;
-  hipEvent_t decoded = nullptr, copied = nullptr;
+  hipEvent_t decoded = nullptr, copied = nullptr, pushed = nullptr;   // head decoded / on the host / delta on the device
   bool running = false;
 };
 
@@ -663,6 +663,7 @@ static LossTask* loss_task_of(layer* l)
     LossTask* t = new LossTask();
     CHECK_HIP(hipEventCreateWithFlags(&t->decoded, hipEventDisableTiming));
     CHECK_HIP(hipEventCreateWithFlags(&t->copied, hipEventDisableTiming));
+    CHECK_HIP(hipEventCreateWithFlags(&t->pushed, hipEventDisableTiming));
     l->loss_task = t;
   }
   return (LossTask*)l->loss_task;
@@ -677,6 +678,7 @@ void DkFreeLossTask(layer* l)
     t->fut.wait();
   (void)hipEventDestroy(t->decoded);
   (void)hipEventDestroy(t->copied);
+  (void)hipEventDestroy(t->pushed);
   delete t;
   l->loss_task = nullptr;
 }
@@ -708,11 +710,18 @@ void DkYoloTrainDelta(layer* l, NetworkState state)
   const int dev = cuda_get_device();
   const int net_w = state.net->w, net_h = state.net->h;
   const float* truth = state.net->truth;
-  hipEvent_t copied = t->copied;
-  t->fut = std::async(std::launch::async, [l, dev, net_w, net_h, truth, copied]() {
+  hipEvent_t copied = t->copied, pushed = t->pushed;
+  t->fut = std::async(std::launch::async, [l, dev, net_w, net_h, truth, copied, pushed, cs, total]() {
     (void)hipSetDevice(dev);
     CHECK_HIP(hipEventSynchronize(copied));
-    return DkYoloLossHost(l, net_w, net_h, l->output, truth, l->delta);
+    const float cost = DkYoloLossHost(l, net_w, net_h, l->output, truth, l->delta);
+    // the delta goes up on the copy stream as soon as it exists (the big head's loss finishes while the GPU is
+    // still in the forward pass), so the backward sweep only waits for an event instead of 62 MB of PCIe traffic;
+    // delta_gpu has no other writer between the step's arena clear (long done: the decode came after it) and
+    // the layer's backward
+    CHECK_HIP(hipMemcpyAsync(l->delta_gpu, l->delta, total * sizeof(float), hipMemcpyHostToDevice, cs));
+    CHECK_HIP(hipEventRecord(pushed, cs));
+    return cost;
   });
   t->running = true;
 }
@@ -725,8 +734,7 @@ static void DkYoloLossJoin(layer* l)
     return;
   *(l->cost) = t->fut.get();
   t->running = false;
-  CHECK_HIP(hipMemcpyAsync(l->delta_gpu, l->delta, (size_t)l->batch * l->outputs * sizeof(float),
-      hipMemcpyHostToDevice, get_cuda_stream()));
+  CHECK_HIP(hipStreamWaitEvent(get_cuda_stream(), t->pushed, 0));   // the upload was enqueued by the loss task
 }
 
 static void backward_range(Network* net, NetworkState state, int hi, int lo)
