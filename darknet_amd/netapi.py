@@ -87,9 +87,14 @@ class DkNet:
         return out.reshape(f["batch"], f["outputs"])
 
     def boxes(self, b, thresh, max_dets=400000):
-        classes = self.info(self.n - 1)["classes"]
-        d = np.zeros((max_dets, 5 + classes), np.float32)
-        ids = np.zeros((max_dets, 4), np.int32)
+        # the record buffers are kept between calls (a caller in a frame loop must not pay for 0.7 MB of
+        # page-zeroing per image); DkGetBoxesBatch writes every field of the n records it returns
+        if getattr(self, "_box_cap", 0) != max_dets:
+            self._classes = self.info(self.n - 1)["classes"]
+            self._box_d = np.zeros((max_dets, 5 + self._classes), np.float32)
+            self._box_ids = np.zeros((max_dets, 4), np.int32)
+            self._box_cap = max_dets
+        d, ids = self._box_d, self._box_ids
         n = self.L.DkGetBoxesBatch(self.p, b, C.c_float(thresh), d.ctypes.data,
                                    ids.ctypes.data_as(C.POINTER(C.c_int)), max_dets)
         assert 0 <= n <= max_dets
