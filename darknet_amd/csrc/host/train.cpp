@@ -350,10 +350,13 @@ struct WgradStream
   bool pending = false;
 };
 
+static int g_train_streams = -1;   // -1: DK_TRAIN_STREAMS (default on)
+extern "C" LIB_API void DkSetTrainStreams(int on) { g_train_streams = on; }
+
 static bool train_streams_on()
 {
-  static const bool on = !(getenv("DK_TRAIN_STREAMS") && !atoi(getenv("DK_TRAIN_STREAMS")));
-  return on;
+  static const bool env_on = !(getenv("DK_TRAIN_STREAMS") && !atoi(getenv("DK_TRAIN_STREAMS")));
+  return g_train_streams >= 0 ? g_train_streams != 0 : env_on;
 }
 
 // the stream this layer's weight gradient goes to, ordered behind everything enqueued on `st` so far

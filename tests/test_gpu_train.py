@@ -529,14 +529,17 @@ def test_split_train_step_equals_train_network_datum(gpu, tmp_path):
 
 def test_derived_weights_launch_equals_per_layer_form(gpu, tmp_path):
     """From the second step on, the transposed / rotated / tap-major data-gradient weights and the Winograd filters
-    come from ONE launch per step (DkTrainPrepRun) into per-layer buffers.  Three steps with that form and three with
-    the per-layer launches (DkSetTrainPrep(0)) must train the same network: the tensors are copies / the same
-    transform of the same weights, so the only difference left is the float-atomic order of the weight gradient."""
+    come from ONE launch per step (DkTrainPrepRun) into per-layer buffers, and the weight gradients run on a second
+    stream.  Three steps in that form and three with the per-layer launches on one stream (DkSetTrainPrep(0),
+    DkSetTrainStreams(0)) must train the same network: the tensors are copies / the same transform of the same
+    weights and the streams only reorder independent kernels, so the only difference left is the float-atomic order
+    of the weight gradient."""
     g, cfg, wpath, x = train_fixture(tmp_path)
     L = gpu.lib()
     for fn, at, rt in (("TrainNetworkDatum", [VP, VP, VP], C.c_float), ("UpdateNetworkGpu", [VP], None),
                        ("DkAdvanceIteration", [VP], None), ("DkSetMaxIter", [VP, C.c_int], None),
-                       ("DkSetTrainPrep", [C.c_int], None), ("DkLayerTrainCfg", [VP, C.c_int, C.c_int], C.c_int),
+                       ("DkSetTrainPrep", [C.c_int], None), ("DkSetTrainStreams", [C.c_int], None),
+                       ("DkLayerTrainCfg", [VP, C.c_int, C.c_int], C.c_int),
                        ("DkLayerPull", [VP, C.c_int, C.c_int, VP, C.c_size_t], C.c_long)):
         getattr(L, fn).argtypes = at
         getattr(L, fn).restype = rt
@@ -546,6 +549,7 @@ def test_derived_weights_launch_equals_per_layer_form(gpu, tmp_path):
     try:
         for mode in (1, 0):
             L.DkSetTrainPrep(mode)
+            L.DkSetTrainStreams(mode)
             net = netutil.DkNet(gpu, cfg, wpath, train=True)
             L.DkSetMaxIter(net.p, 1000)
             costs = []
@@ -565,6 +569,7 @@ def test_derived_weights_launch_equals_per_layer_form(gpu, tmp_path):
             net.close()
     finally:
         L.DkSetTrainPrep(-1)
+        L.DkSetTrainStreams(-1)
     (ca, wa, ka), (cb, wb, kb) = res[1], res[0]
     assert ka == kb and len(ka) >= 3      # same kernel choices (process-wide timing cache), several kinds of them
     assert np.allclose(ca, cb, rtol=1e-4), (ca, cb)
