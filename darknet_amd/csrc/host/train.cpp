@@ -352,6 +352,7 @@ struct WgradStream
 
 static int g_train_streams = -1;   // -1: DK_TRAIN_STREAMS (default on)
 extern "C" LIB_API void DkSetTrainStreams(int on) { g_train_streams = on; }
+extern "C" LIB_API void DkSetDeterministic(int on) { dk_set_deterministic(on); }
 
 static bool train_streams_on()
 {
@@ -574,6 +575,14 @@ void BackwardMaxpoolLayerGpu(layer* l, NetworkState state)
 {
   if (!state.delta)
     return;
+  if (dk_deterministic())
+  {
+    // (float atomics over the overlapping windows of the stride-1 SPP pools would make the step irreproducible)
+    if (dk_maxpool_backward_gather(l->delta_gpu, l->indexes_gpu, l->batch, l->c, l->h, l->w, l->out_h, l->out_w, l->size,
+            l->stride_x, l->stride_y, l->pad, state.delta, get_cuda_stream()))
+      error("maxpool backward failed");
+    return;
+  }
   dk_maxpool_backward(l->delta_gpu, l->indexes_gpu, (size_t)l->batch * l->outputs, state.delta,
       get_cuda_stream());
 }

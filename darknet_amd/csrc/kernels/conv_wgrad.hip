@@ -21,6 +21,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "dark_hip.h"
 #include "dk_kernels.h"
 #include "dk_internal.h"
@@ -43,6 +45,10 @@ struct WgradArgs
   int N;               // batch*OHW
   int size, stride_x, stride_y, pad, dil;
   int tiles_m, tiles_k, nsplit, stages_per_split, groups;
+  // deterministic mode (dk_set_deterministic): every pixel split stores its tile into its own slice of a workspace
+  // ([split][the dW index space], plain stores) and wgrad_reduce_kernel adds the slices in ascending split order
+  float* part;
+  unsigned long long part_stride;
 };
 
 constexpr unsigned OOB = 0x80000000u;
@@ -289,24 +295,60 @@ __global__ void __launch_bounds__(T) conv_wgrad_f32(const WgradArgs p)
   }
 
   // C/D: col (= k) = lane&31, row (= m) = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // TMAJ accumulates into a tap-major workspace [m][t][c] (consecutive lanes = consecutive addresses: the float
+  // atomics stay coalesced; scattered to [c][kh][kw] directly they ran 2.4x slower); wgrad_fold_kernel adds the
+  // workspace into dW afterwards.  One launch-uniform branch selects plain stores into this split's slice of the
+  // partial workspace (deterministic mode) or the atomics; the loops are written out twice so that the default
+  // path's epilogue is exactly the code it was.
+  auto emit = [&](auto detc) {
+    constexpr bool DET = decltype(detc)::value;
+    float* const dst = DET ? p.part + (size_t)split * p.part_stride : p.dw;
 #pragma unroll
-  for (int j = 0; j < TK; ++j)
+    for (int j = 0; j < TK; ++j)
+    {
+      const int k = k0 + (wk * TK + j) * 32 + l31;
+      if (k >= p.K)
+        continue;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+        {
+          const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m < p.M)
+          {
+            if (DET)
+              dst[((size_t)g * p.M + m) * p.K + k] = acc[i][j][r];
+            else
+              atomicAdd(&dst[((size_t)g * p.M + m) * p.K + k], acc[i][j][r]);
+          }
+        }
+    }
+  };
+  if (p.part)
+    emit(std::true_type{});
+  else
+    emit(std::false_type{});
+}
+
+// deterministic mode: dW[i] += sum over the pixel splits, ascending, of their partial tiles (tap-major partials are
+// un-permuted on the way, as wgrad_fold_kernel does for the atomic form)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, size_t stride, float* __restrict__ dw,
+    int C, int ss, size_t total, int tmaj)
+{
+  const size_t K = (size_t)C * ss;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
   {
-    // TMAJ accumulates into a tap-major workspace [m][t][c] (consecutive lanes = consecutive addresses: the float
-    // atomics stay coalesced; scattered to [c][kh][kw] directly they ran 2.4x slower); wgrad_fold_kernel adds the
-    // workspace into dW afterwards
-    const int k = k0 + (wk * TK + j) * 32 + l31;
-    if (k >= p.K)
-      continue;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-      {
-        const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m < p.M)
-          atomicAdd(&p.dw[((size_t)g * p.M + m) * p.K + k], acc[i][j][r]);
-      }
+    size_t src = i;
+    if (tmaj)
+    {
+      const size_t m = i / K, r = i - m * K;
+      const int c = (int)(r / ss), t = (int)(r - (size_t)c * ss);
+      src = m * K + (size_t)t * C + c;
+    }
+    float s = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) s += part[(size_t)sp * stride + src];
+    dw[i] += s;
   }
 }
 
@@ -347,6 +389,29 @@ float* wgrad_workspace(size_t floats, hipStream_t st)
   return buf[dev];
 }
 
+// partial-tile workspace of the deterministic form (per device, grown on demand; contents never assumed)
+float* wgrad_part_workspace(size_t floats, hipStream_t st)
+{
+  static float* buf[64] = {nullptr};
+  static size_t cap[64] = {0};
+  int dev = 0;
+  CHECK_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64)
+    dev = 0;
+  if (cap[dev] < floats)
+  {
+    if (buf[dev])
+    {
+      CHECK_HIP(hipDeviceSynchronize());
+      CHECK_HIP(hipFree(buf[dev]));
+    }
+    CHECK_HIP(hipMalloc((void**)&buf[dev], floats * sizeof(float)));
+    cap[dev] = floats;
+  }
+  (void)st;
+  return buf[dev];
+}
+
 typedef void (*WgradKernel)(const WgradArgs);
 struct WgradCfg
 {
@@ -359,6 +424,18 @@ struct WgradCfg
 const WgradCfg g_wcfg[] = {DK_WG(2, 2), DK_WG(1, 2), DK_WG(2, 1), DK_WG(1, 1)};
 #undef DK_WG
 }  // namespace
+
+// Deterministic reductions (weight gradients here, BN channel sums in train_ops.hip): partial results go to
+// workspaces and are added in a fixed order instead of through float / double atomics, so two runs of a step with
+// the same kernel choices are bitwise equal.  Off by default (the weight gradient grows by the partial traffic);
+// DK_DETERMINISTIC=1 or dk_set_deterministic(1).
+static int g_deterministic = -1;
+extern "C" void dk_set_deterministic(int on) { g_deterministic = on; }
+bool dk_deterministic()
+{
+  static const bool env_on = getenv("DK_DETERMINISTIC") && atoi(getenv("DK_DETERMINISTIC"));
+  return g_deterministic >= 0 ? g_deterministic != 0 : env_on;
+}
 
 extern "C" int dk_conv_backward_weights(const DkConvDesc* d, const float* x, const float* delta,
     float* weight_updates, void* stream)
@@ -444,7 +521,15 @@ int dk_conv_backward_weights_cfg(const DkConvDesc* d, const float* x, const floa
     // (a 1x1 layer is its own tap-major order: same fast gather, no workspace)
     const bool tmaj = tmaj_on && (C % BKO) == 0 && d->pad * d->dilation == (d->size > 1 ? d->pad * d->dilation : 0);
     const int kv = (avec ? 1 : 0) + (tmaj ? 2 : 0);
-    if (tmaj && d->size > 1)
+    const bool det = dk_deterministic();
+    a.part = nullptr;
+    a.part_stride = 0;
+    if (det)
+    {
+      a.part_stride = (unsigned long long)d->n * K;
+      a.part = wgrad_part_workspace((size_t)a.nsplit * a.part_stride, st);
+    }
+    else if (tmaj && d->size > 1)
     {
       if (!ws)
         ws = wgrad_workspace((size_t)d->n * K, st);
@@ -461,6 +546,15 @@ int dk_conv_backward_weights_cfg(const DkConvDesc* d, const float* x, const floa
       char nm[96];
       snprintf(nm, sizeof(nm), "conv_wgrad_f32<%d, %d, %s, %s>", c.tm, c.tk, avec ? "true" : "false", tmaj ? "true" : "false");
       dk_prof_end(prof, st, dk_prof_named_slot(nm), 2.0 * (double)M * K * d->groups * (double)a.N / 1e9);
+    }
+    if (det)
+    {
+      const size_t total = (size_t)d->n * K;
+      unsigned gb = (unsigned)((total + 255) / 256);
+      if (gb > 8192u) gb = 8192u;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gb), dim3(256), 0, st, a.part, a.nsplit, (size_t)a.part_stride,
+          weight_updates, C, d->size * d->size, total, (tmaj && d->size > 1) ? 1 : 0);
+      CHECK_HIP(hipPeekAtLastError());
     }
   }
   if (ws)

@@ -92,3 +92,6 @@ struct DkPrepTask
 void* dk_train_prep_create(int ntasks, DkPrepTask* host_tasks);
 void dk_train_prep_destroy(void* plan);
 int dk_train_prep_run(void* plan, void* stream);
+
+// deterministic reductions requested (dk_set_deterministic / DK_DETERMINISTIC): see conv_wgrad.hip
+bool dk_deterministic();

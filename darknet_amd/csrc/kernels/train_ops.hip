@@ -143,7 +143,7 @@ inline void plane_split2(int batch, int filters, int spatial, int* cps, int* sli
 
 // sums NV doubles over the workgroup (RP threads) and adds them to dst[0..NV) with fp64 atomics:
 // wave shuffles, one LDS exchange, one barrier
-template <int NV>
+template <int NV, bool STORE = false>
 __device__ __forceinline__ void block_reduce_atomic(double (&v)[NV], double* __restrict__ dst)
 {
   __shared__ double sh[NV * (RP / 64)];
@@ -163,8 +163,35 @@ __device__ __forceinline__ void block_reduce_atomic(double (&v)[NV], double* __r
     double r = 0;
 #pragma unroll
     for (int i = 0; i < RP / 64; ++i) r += sh[threadIdx.x * (RP / 64) + i];
-    atomicAdd(&dst[threadIdx.x], r);
+    if (STORE)
+      dst[threadIdx.x] = r;     // deterministic mode: this workgroup's own slot
+    else
+      atomicAdd(&dst[threadIdx.x], r);
   }
+}
+
+// The NV sums of channel f, for the first wave of a consumer workgroup (all 64 lanes call; the result is valid on
+// lane 0).  nwg == 0: the atomics layout [f][NV]; nwg > 0 (deterministic mode): the partials [f][nwg][NV] of the nwg
+// producer workgroups, added lane-strided and then across the wave -- a fixed order for a fixed nwg.
+template <int NV>
+__device__ __forceinline__ void chan_sums(const double* __restrict__ sums, int f, int nwg, double (&out)[NV])
+{
+  if (nwg == 0)
+  {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) out[k] = sums[NV * f + k];
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) out[k] = 0;
+  for (int w = lane; w < nwg; w += 64)
+#pragma unroll
+    for (int k = 0; k < NV; ++k) out[k] += sums[((size_t)f * nwg + w) * NV + k];
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) out[k] += __shfl_down(out[k], o, 64);
 }
 
 __device__ __forceinline__ double block_sum(double v, double* sh)
@@ -202,7 +229,7 @@ __device__ __forceinline__ size_t chan_index(size_t t, int f, int filters, int s
 // (the reference's N-1 denominator, src/blas.c:186; evaluated in double, so the
 // one-pass form loses nothing), rolling statistics .9/.1.
 __global__ void __launch_bounds__(RP) bn_partial_kernel(const float* __restrict__ x, int batch,
-    int filters, int spatial, int cps, int slice, int ipw, double* __restrict__ scratch)
+    int filters, int spatial, int cps, int slice, int ipw, double* __restrict__ scratch, int det)
 {
   const int f = blockIdx.y;
   const int bg = blockIdx.x / cps, ch = blockIdx.x - bg * cps;
@@ -257,7 +284,10 @@ __global__ void __launch_bounds__(RP) bn_partial_kernel(const float* __restrict_
       }
     }
   }
-  block_reduce_atomic<2>(acc, scratch + 2 * f);
+  if (det)
+    block_reduce_atomic<2, true>(acc, scratch + ((size_t)f * gridDim.x + blockIdx.x) * 2);
+  else
+    block_reduce_atomic<2>(acc, scratch + 2 * f);
 }
 
 // normalize_cpu (eps 1e-6) + scale_bias + add_bias + activation, one pass.
@@ -282,7 +312,7 @@ __global__ void bn_apply_kernel(const float* __restrict__ raw, float* __restrict
     float* __restrict__ mean, float* __restrict__ variance,
     const float* __restrict__ scales, const float* __restrict__ biases, int filters, int spatial,
     int act, int vec, const double* __restrict__ sums, int batch, float* __restrict__ rolling_mean,
-    float* __restrict__ rolling_variance)
+    float* __restrict__ rolling_variance, int nwg)
 {
   const int plane = blockIdx.x;
   const int f = plane % filters;
@@ -290,10 +320,13 @@ __global__ void bn_apply_kernel(const float* __restrict__ raw, float* __restrict
   if (sums)
   {
     __shared__ float stat[2];
+    double sq[2] = {0, 0};
+    if (threadIdx.x < 64)
+      chan_sums<2>(sums, f, nwg, sq);
     if (threadIdx.x == 0)
     {
       const double n = (double)batch * spatial;
-      const double s = sums[2 * f], q = sums[2 * f + 1];
+      const double s = sq[0], q = sq[1];
       const float mm = (float)(s / n);
       double v = (q - s * s / n) / (n - 1);
       if (v < 0)
@@ -540,7 +573,7 @@ __device__ __forceinline__ BnRecompute bn_recompute(float x, float delta, float 
 __global__ void __launch_bounds__(RP) bn_act_partial_kernel(const float* __restrict__ delta,
     const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ variance,
     const float* __restrict__ scales, const float* __restrict__ biases, int batch, int filters,
-    int spatial, int cps, int slice, int ipw, double* __restrict__ scratch, int act)
+    int spatial, int cps, int slice, int ipw, double* __restrict__ scratch, int act, int det)
 {
   const int f = blockIdx.y;
   const int bg = blockIdx.x / cps, ch = blockIdx.x - bg * cps;
@@ -595,7 +628,10 @@ __global__ void __launch_bounds__(RP) bn_act_partial_kernel(const float* __restr
       for (; i < i1; i += RP) one(x[base + i], delta[base + i]);
     }
   }
-  block_reduce_atomic<4>(acc, scratch + 4 * f);
+  if (det)
+    block_reduce_atomic<4, true>(acc, scratch + ((size_t)f * gridDim.x + blockIdx.x) * 4);
+  else
+    block_reduce_atomic<4>(acc, scratch + 4 * f);
 }
 
 // grid (batch*filters, chunks): one (image, channel) plane per blockIdx.x -> no per-element division.
@@ -611,7 +647,7 @@ __global__ void bn_act_delta_kernel(float* __restrict__ delta, const float* __re
     float* __restrict__ mean_delta, float* __restrict__ variance_delta,
     const float* __restrict__ scales, const float* __restrict__ biases, int batch, int filters,
     int spatial, int act, int vec, const double* __restrict__ sums, float* __restrict__ bias_updates,
-    float* __restrict__ scale_updates)
+    float* __restrict__ scale_updates, int nwg)
 {
   const int plane = blockIdx.x;
   const int f = plane % filters;
@@ -619,11 +655,14 @@ __global__ void bn_act_delta_kernel(float* __restrict__ delta, const float* __re
   const float sc = scales[f], bi = biases[f], m = mean[f], var = variance[f];
   const float div = sqrtf(var + .000001f);
   __shared__ float fin[2];
+  double s4[4] = {0, 0, 0, 0};
+  if (threadIdx.x < 64)
+    chan_sums<4>(sums, f, nwg, s4);
   if (threadIdx.x == 0)
   {
-    float md = (float)sums[4 * f + 2];
+    float md = (float)s4[2];
     md *= (-1. / sqrtf(var + .00001f));
-    float vd = (float)sums[4 * f + 3];
+    float vd = (float)s4[3];
     vd *= -.5 * powf(var + .00001f, (float)(-3. / 2.));
     fin[0] = md;
     fin[1] = vd;
@@ -631,8 +670,8 @@ __global__ void bn_act_delta_kernel(float* __restrict__ delta, const float* __re
     {
       mean_delta[f] = md;
       variance_delta[f] = vd;
-      bias_updates[f] += (float)sums[4 * f + 0];
-      scale_updates[f] += (float)sums[4 * f + 1];
+      bias_updates[f] += (float)s4[0];
+      scale_updates[f] += (float)s4[1];
     }
   }
   __syncthreads();
@@ -686,6 +725,38 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ delta, const int* _
     const int idx = indexes[i];
     if (idx >= 0)
       atomicAdd(&prev_delta[idx], delta[i]);  // stride-1 SPP windows overlap
+  }
+}
+
+// The same gradient as a gather (deterministic mode): every INPUT element visits the windows that contain it, in
+// row-major window order, and adds the deltas of those whose argmax it is.  No atomics; an input element of a
+// k x k / stride-1 pool checks k*k windows (the SPP block: 25 / 81 / 169 on 19x19 maps).
+__global__ void maxpool_bwd_gather_kernel(const float* __restrict__ delta, const int* __restrict__ indexes,
+    size_t total_in, int h, int w, int out_h, int out_w, int size, int stride_x, int stride_y, int pad,
+    float* __restrict__ prev_delta)
+{
+  const int off = pad / 2;
+  for (size_t id = blockIdx.x * (size_t)blockDim.x + threadIdx.x; id < total_in; id += (size_t)gridDim.x * blockDim.x)
+  {
+    const int ix = (int)(id % w);
+    const size_t t = id / w;
+    const int iy = (int)(t % h);
+    const size_t plane = t / h;
+    // windows (oy, ox) with oy*stride - off <= iy < oy*stride - off + size
+    int oy0 = (iy + off - size + stride_y) / stride_y, oy1 = (iy + off) / stride_y;
+    int ox0 = (ix + off - size + stride_x) / stride_x, ox1 = (ix + off) / stride_x;
+    if (iy + off - size + 1 <= 0) oy0 = 0;
+    if (ix + off - size + 1 <= 0) ox0 = 0;
+    if (oy1 > out_h - 1) oy1 = out_h - 1;
+    if (ox1 > out_w - 1) ox1 = out_w - 1;
+    const int* ip = indexes + plane * (size_t)out_h * out_w;
+    const float* dp = delta + plane * (size_t)out_h * out_w;
+    float s = 0.f;
+    for (int oy = oy0; oy <= oy1; ++oy)
+      for (int ox = ox0; ox <= ox1; ++ox)
+        if (ip[oy * out_w + ox] == (int)id)
+          s += dp[oy * out_w + ox];
+    prev_delta[id] += s;
   }
 }
 
@@ -882,18 +953,21 @@ extern "C" int dk_bn_forward_train(const float* raw, float* x_save, float* x_nor
     activation |= DK_ACT_FAST;
   hipStream_t st = S(stream);
   double* sums = nullptr;
+  int nwg = 0;
   if (train)
   {
-    sums = chan_ring_take((size_t)2 * filters, st);
+    int cps, slice, ipw;
+    plane_split2(batch, filters, spatial, &cps, &slice, &ipw);
+    const int gx = cps * ((batch + ipw - 1) / ipw);
+    nwg = dk_deterministic() ? gx : 0;   // deterministic mode: one slot per producer workgroup, summed in order
+    sums = chan_ring_take((size_t)2 * filters * (nwg ? nwg : 1), st);
     if (!sums)
     {
       fprintf(stderr, "dk_bn_forward_train: too many channels\n");
       return 1;
     }
-    int cps, slice, ipw;
-    plane_split2(batch, filters, spatial, &cps, &slice, &ipw);
-    hipLaunchKernelGGL(bn_partial_kernel, dim3(cps * ((batch + ipw - 1) / ipw), filters), dim3(RP), 0, st, raw, batch,
-        filters, spatial, cps, slice, ipw, sums);
+    hipLaunchKernelGGL(bn_partial_kernel, dim3(gx, filters), dim3(RP), 0, st, raw, batch,
+        filters, spatial, cps, slice, ipw, sums, nwg ? 1 : 0);
     CHECK_HIP(hipPeekAtLastError());
   }
   {
@@ -905,7 +979,7 @@ extern "C" int dk_bn_forward_train(const float* raw, float* x_save, float* x_nor
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(bn_apply_kernel, dim3(batch * filters, gx), dim3(256), 0, st, raw, xs, xn, act_in, out,
         train ? mean : rolling_mean, train ? variance : rolling_variance, scales, biases, filters, spatial,
-        activation, vec, (const double*)sums, batch, rolling_mean, rolling_variance);
+        activation, vec, (const double*)sums, batch, rolling_mean, rolling_variance, nwg);
   }
   CHECK_HIP(hipPeekAtLastError());
   return 0;
@@ -937,6 +1011,11 @@ extern "C" int dk_backward_bias(float* bias_updates, const float* delta, int bat
   int chunks;
   size_t slice;
   chan_split(batch, n, size, &chunks, &slice);
+  if (dk_deterministic())
+  {
+    chunks = 1;   // one workgroup per channel: its block sum has a fixed order, the single atomic lands on zero
+    slice = (size_t)batch * size;
+  }
   hipLaunchKernelGGL(chan_partial_kernel, dim3(chunks, n), dim3(RT), 0, st, delta, nullptr, nullptr,
       nullptr, nullptr, batch, n, size, slice, scratch, 0);
   hipLaunchKernelGGL(chan_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, st, scratch, nullptr,
@@ -957,6 +1036,11 @@ extern "C" int dk_bn_backward(float* delta, const float* x, const float* x_norm,
   int chunks;
   size_t slice;
   chan_split(batch, filters, spatial, &chunks, &slice);
+  if (dk_deterministic())
+  {
+    chunks = 1;
+    slice = (size_t)batch * spatial;
+  }
   hipLaunchKernelGGL(chan_partial_kernel, dim3(chunks, filters), dim3(RT), 0, st, delta, x, x_norm,
       mean, scales, batch, filters, spatial, slice, scratch, 1);
   hipLaunchKernelGGL(chan_finalize_kernel, dim3((filters + 255) / 256), dim3(256), 0, st, scratch,
@@ -981,23 +1065,25 @@ extern "C" int dk_bn_act_backward(float* delta, const float* x, const float* mea
   hipStream_t st = S(stream);
   if (activation == DK_MISH && dk_fast_mish_enabled())
     activation |= DK_ACT_FAST;
-  double* sums = chan_ring_take((size_t)4 * filters, st);
+  int cps, slice, ipw;
+  plane_split2(batch, filters, spatial, &cps, &slice, &ipw);
+  const int gpx = cps * ((batch + ipw - 1) / ipw);
+  const int nwg = dk_deterministic() ? gpx : 0;
+  double* sums = chan_ring_take((size_t)4 * filters * (nwg ? nwg : 1), st);
   if (!sums)
   {
     fprintf(stderr, "dk_bn_act_backward: too many channels\n");
     return 1;
   }
-  int cps, slice, ipw;
-  plane_split2(batch, filters, spatial, &cps, &slice, &ipw);
-  hipLaunchKernelGGL(bn_act_partial_kernel, dim3(cps * ((batch + ipw - 1) / ipw), filters), dim3(RP), 0, st, delta, x, mean,
-      variance, scales, biases, batch, filters, spatial, cps, slice, ipw, sums, activation);
+  hipLaunchKernelGGL(bn_act_partial_kernel, dim3(gpx, filters), dim3(RP), 0, st, delta, x, mean,
+      variance, scales, biases, batch, filters, spatial, cps, slice, ipw, sums, activation, nwg ? 1 : 0);
   const int vec = ((spatial & 3) == 0 && ((((uintptr_t)delta) | ((uintptr_t)x)) & 15) == 0) ? 1 : 0;
   // one 256-thread workgroup streams up to 8 K elements of its plane (two 16-byte positions in flight per thread)
   int gx = vec ? (spatial + 8191) / 8192 : (spatial + 1023) / 1024;
   if (gx > 64) gx = 64;
   hipLaunchKernelGGL(bn_act_delta_kernel, dim3(batch * filters, gx), dim3(256), 0, st, delta, x, mean,
       variance, mean_delta, variance_delta, scales, biases, batch, filters, spatial, activation, vec,
-      (const double*)sums, bias_updates, scale_updates);
+      (const double*)sums, bias_updates, scale_updates, nwg);
   CHECK_HIP(hipPeekAtLastError());
   return 0;
 }
@@ -1009,6 +1095,24 @@ extern "C" int dk_maxpool_backward(const float* delta, const int* indexes, size_
     return 0;
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), delta, indexes,
       n, prev_delta);
+  CHECK_HIP(hipPeekAtLastError());
+  return 0;
+}
+
+// deterministic form (needs the layer's geometry): see maxpool_bwd_gather_kernel
+extern "C" int dk_maxpool_backward_gather(const float* delta, const int* indexes, int batch, int c, int h, int w, int out_h,
+    int out_w, int size, int stride_x, int stride_y, int pad, float* prev_delta, void* stream)
+{
+  const size_t total_in = (size_t)batch * c * h * w;
+  if (total_in == 0)
+    return 0;
+  if (total_in >= ((size_t)1 << 31))
+  {
+    fprintf(stderr, "dk_maxpool_backward_gather: tensor too large for the int argmax indices\n");
+    return 1;
+  }
+  hipLaunchKernelGGL(maxpool_bwd_gather_kernel, dim3(grid_for(total_in)), dim3(256), 0, S(stream), delta, indexes,
+      total_in, h, w, out_h, out_w, size, stride_x, stride_y, pad, prev_delta);
   CHECK_HIP(hipPeekAtLastError());
   return 0;
 }

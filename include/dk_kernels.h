@@ -216,6 +216,9 @@ DK_API int dk_conv_backward_data(const DkConvDesc* d, const float* delta, const 
     float* prev_delta, void* stream);
 /* wt[g][c][(m,kh,kw)] = w[g][m][c][kh][kw]; call per group with M = n/groups, C = c/groups */
 DK_API int dk_transpose_weights(const float* w, float* wt, int M, int C, int size, void* stream);
+/* 1: weight gradients and BN channel sums through ordered workspaces instead of atomics (two runs of a training step
+ * with the same kernel choices are then bitwise equal); 0: atomics (default, faster); -1: follow DK_DETERMINISTIC */
+DK_API void dk_set_deterministic(int on);
 /* Stride-2 layers (both directions, even input dimensions, one group, filters a multiple of 32, size 2 or 3): the
  * same data gradient with the pixels enumerated parity class by parity class and the contraction index tap-major
  * (wt = dk_transpose_weights_tapmajor(weights): wt[c][t * n + m] = w[m][c][t]), so that only the taps whose parity
@@ -227,6 +230,10 @@ DK_API int dk_transpose_weights_tapmajor(const float* w, float* wt, int M, int C
 /* backward_maxpool_layer_kernel, src/maxpool_layer_kernels.cu:103-143 (scatter-add by index) */
 DK_API int dk_maxpool_backward(const float* delta, const int* indexes, size_t n,
     float* prev_delta, void* stream);
+/* The same gradient without atomics (deterministic mode): every input element visits the windows that contain it in
+ * row-major order.  Needs the layer geometry (`pad` as in dk_maxpool_forward: the window starts at -pad/2). */
+DK_API int dk_maxpool_backward_gather(const float* delta, const int* indexes, int batch, int c, int h, int w,
+    int out_h, int out_w, int size, int stride_x, int stride_y, int pad, float* prev_delta, void* stream);
 /* one source of BackwardRouteLayerGpu, src/route_layer.c:144-160 */
 DK_API int dk_route_backward(const float* delta, int outputs, int offset, int input_size,
     int groups, int group_id, int batch, float* src_delta, void* stream);

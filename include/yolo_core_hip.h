@@ -450,6 +450,7 @@ LIB_API void DkBackwardRange(Network* net, int hi, int lo);
 LIB_API float DkTrainFinish(Network* net);
 LIB_API size_t DkGradBucketOffset(Network* net, int upto_layer);
 LIB_API void DkAdvanceIteration(Network* net);
+LIB_API void DkSetDeterministic(int on); /* 1: ordered reductions instead of atomics in the train step (dk_set_deterministic) */
 LIB_API void DkSetTrainStreams(int on); /* 1 (default): weight gradients on the network's second stream; 0: one stream */
 LIB_API void DkSetTrainPrep(int on); /* 1 (default): derived weight tensors of a train step in one launch; 0: per layer */
 LIB_API void DkSetCurrIter(Network* net, long long iter); /* net->curr_iter = iter (GetCurrLr / burn-in / stopbackward schedules) */

@@ -577,6 +577,104 @@ def test_derived_weights_launch_equals_per_layer_form(gpu, tmp_path):
         util.assert_close(wa[i], wb[i], "weights of conv %d after three steps" % i, rel=1e-4, atol_rms=1e-5)
 
 
+def test_maxpool_backward_gather_equals_scatter(gpu):
+    """dk_maxpool_backward_gather (deterministic mode: no atomics) == dk_maxpool_backward on the SPP pools (stride 1,
+    windows 5 / 9 / 13 on 19x19: overlapping windows, the case the atomics exist for) and on 2x2 / stride-2 pools,
+    incl. odd maps.  Integer-valued deltas make the atomic sum order irrelevant, so the comparison is exact."""
+    G = bind(gpu.lib())
+    L = gpu.lib()
+    i = C.c_int
+    L.dk_maxpool_forward.argtypes = [VP, VP, VP, i, i, i, i, i, i, i, i, VP]
+    L.dk_maxpool_forward.restype = i
+    L.dk_maxpool_backward_gather.argtypes = [VP, VP, i, i, i, i, i, i, i, i, i, i, VP, VP]
+    L.dk_maxpool_backward_gather.restype = i
+    rng = np.random.default_rng(21)
+    for batch, c, h, w, size, stride in ((2, 6, 19, 19, 5, 1), (1, 4, 19, 19, 9, 1), (2, 3, 19, 19, 13, 1),
+                                         (2, 8, 26, 26, 2, 2), (1, 5, 13, 13, 2, 1), (2, 4, 15, 17, 3, 2)):
+        pad = size - 1
+        oh, ow = (h + pad - size) // stride + 1, (w + pad - size) // stride + 1
+        x = rng.uniform(-1, 1, (batch, c, h, w)).astype(np.float32)
+        delta = rng.integers(-8, 9, (batch, c, oh, ow)).astype(np.float32)
+        dx, dy, didx = gpu.DeviceArray(x), gpu.DeviceArray(n=batch * c * oh * ow), gpu.DeviceArray(n=batch * c * oh * ow)
+        assert L.dk_maxpool_forward(dx.ptr, dy.ptr, didx.ptr, batch, c, h, w, size, stride, stride, pad, None) == 0
+        dd = gpu.DeviceArray(delta)
+        base = rng.integers(-3, 4, x.shape).astype(np.float32)
+        pa, pb = gpu.DeviceArray(base), gpu.DeviceArray(base)
+        assert G.dk_maxpool_backward(dd.ptr, didx.ptr, delta.size, pa.ptr, None) == 0
+        assert L.dk_maxpool_backward_gather(dd.ptr, didx.ptr, batch, c, h, w, oh, ow, size, stride, stride, pad, pb.ptr, None) == 0
+        a, b = pa.numpy(), pb.numpy()
+        assert np.array_equal(a, b), (size, stride, np.abs(a - b).max())
+        assert np.abs(a - base.ravel()).sum() > 0
+
+
+def test_deterministic_mode_is_bitwise_reproducible(gpu, tmp_path):
+    """DkSetDeterministic(1): weight gradients, BN channel sums, bias sums and the maxpool gradient go through ordered
+    workspaces instead of float / double atomics.  Two fresh networks stepped three times on the same data must then
+    agree BITWISE in every weight and in the cost (same process: same kernel choices), the split step must reproduce
+    the unsplit gradients bitwise, and the mode must still train the same network as the default (atomics) mode."""
+    from darknet_amd.train_dist import bucket_segments
+    g, cfg, wpath, x = train_fixture(tmp_path)
+    L = gpu.lib()
+    for fn, at, rt in (("TrainNetworkDatum", [VP, VP, VP], C.c_float), ("UpdateNetworkGpu", [VP], None),
+                       ("DkAdvanceIteration", [VP], None), ("DkSetMaxIter", [VP, C.c_int], None),
+                       ("DkSetDeterministic", [C.c_int], None), ("DkTrainForward", [VP, VP, VP], None),
+                       ("DkBackwardRange", [VP, C.c_int, C.c_int], None), ("DkTrainFinish", [VP], C.c_float),
+                       ("DkGradBucketOffset", [VP, C.c_int], C.c_size_t),
+                       ("DkLayerPull", [VP, C.c_int, C.c_int, VP, C.c_size_t], C.c_long)):
+        getattr(L, fn).argtypes = at
+        getattr(L, fn).restype = rt
+    truth = np.ascontiguousarray(g["truth"])
+    xin = np.ascontiguousarray(x)
+
+    def pull(net, i, which, n):
+        out = np.empty(n, np.float32)
+        assert L.DkLayerPull(net.p, i, which, out.ctypes.data, n) == n
+        return out
+
+    def run(steps=3):
+        net = netutil.DkNet(gpu, cfg, wpath, train=True)
+        L.DkSetMaxIter(net.p, 1000)
+        costs = []
+        for _ in range(steps):
+            costs.append(L.TrainNetworkDatum(net.p, xin.ctypes.data, truth.ctypes.data))
+            L.DkAdvanceIteration(net.p)
+            L.UpdateNetworkGpu(net.p)
+        convs = [i for i in range(net.n) if net.info(i)["type"] == O.CONVOLUTIONAL]
+        w = {i: pull(net, i, 1, net.info(i)["nweights"]) for i in convs}
+        net.close()
+        return costs, w
+
+    try:
+        L.DkSetDeterministic(1)
+        c1, w1 = run()
+        c2, w2 = run()
+        assert c1 == c2, (c1, c2)
+        for i in w1:
+            assert np.array_equal(w1[i].view(np.uint32), w2[i].view(np.uint32)), "conv %d weights differ between two deterministic runs" % i
+        # split step == unsplit step, bitwise
+        a = netutil.DkNet(gpu, cfg, wpath, train=True)
+        cost_a = L.TrainNetworkDatum(a.p, xin.ctypes.data, truth.ctypes.data)
+        b = netutil.DkNet(gpu, cfg, wpath, train=True)
+        offs = [L.DkGradBucketOffset(b.p, i) for i in range(b.n + 1)]
+        convs = [i for i in range(b.n) if offs[i + 1] > offs[i]]
+        segs = bucket_segments(convs, [offs[i + 1] - offs[i] for i in convs], b.n, 3)
+        L.DkTrainForward(b.p, xin.ctypes.data, truth.ctypes.data)
+        for hi, lo, off, cnt in segs:
+            L.DkBackwardRange(b.p, hi, lo)
+        assert L.DkTrainFinish(b.p) == cost_a
+        for i in convs:
+            n = a.info(i)["nweights"]
+            assert np.array_equal(pull(a, i, 7, n).view(np.uint32), pull(b, i, 7, n).view(np.uint32)), i
+        a.close(); b.close()
+        L.DkSetDeterministic(0)
+        c0, w0 = run()
+    finally:
+        L.DkSetDeterministic(-1)
+    assert np.allclose(c0, c1, rtol=1e-4), (c0, c1)
+    for i in w1:
+        util.assert_close(w1[i], w0[i], "deterministic vs atomics, conv %d after three steps" % i, rel=1e-4, atol_rms=1e-5)
+
+
 def test_stopbackward_split_step_equals_unsplit(gpu, tmp_path):
     """`stopbackward=1` (network_kernels.cu:140-143 ends the backward sweep for good): the split step must
     not resume the sweep in the next DkBackwardRange segment -- gradients below the stop layer stay exactly what
