@@ -369,7 +369,11 @@ static hipStream_t wgrad_stream_of(Network* net, bool tuned_before, hipStream_t 
   if (!w)
   {
     w = new WgradStream();
-    CHECK_HIP(hipStreamCreateWithFlags(&w->s, hipStreamNonBlocking));
+    // lowest priority: when both streams have workgroups ready, the critical path (main stream) goes first
+    int prio_least = 0, prio_greatest = 0;
+    CHECK_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    static const bool low = !(getenv("DK_WGRAD_PRIO") && !atoi(getenv("DK_WGRAD_PRIO")));
+    CHECK_HIP(hipStreamCreateWithPriority(&w->s, hipStreamNonBlocking, low ? prio_least : prio_greatest));
     CHECK_HIP(hipEventCreateWithFlags(&w->ready, hipEventDisableTiming));
     CHECK_HIP(hipEventCreateWithFlags(&w->done, hipEventDisableTiming));
     net->wgrad_stream = w;
