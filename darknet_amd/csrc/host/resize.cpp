@@ -73,6 +73,7 @@ void ResizeNetwork(Network* net, int w, int h)
     cuda_free(net->delta_arena_gpu);
     net->delta_arena_gpu = nullptr;
     net->delta_arena_size = 0;
+    net->delta_arena_zero = 0;
   }
   net->w = w;
   net->h = h;
