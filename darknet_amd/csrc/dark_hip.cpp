@@ -3,12 +3,16 @@
 // memcpy stream per device (src/dark_cuda.c:128-177), errors print and exit()
 // (src/dark_cuda.c:85-106).  No cuBLAS/cuDNN/cuRAND handles exist.
 #include "dark_hip.h"
+#include "dk_kernels.h"
 
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+
+#include <atomic>
 
 #include <map>
 #include <mutex>
@@ -293,6 +297,21 @@ DK_EXPORT float cuda_compare(float* x_gpu, float* x, size_t n, char* s)
   printf("Error %s: %f\n", s ? s : "", err / (n ? n : 1));
   free(tmp);
   return (float)err;
+}
+
+DK_EXPORT void cuda_random(float* x_gpu, size_t n)
+{
+  // src/dark_cuda.c:464-477 (curandGenerateUniform with a time(0) seed per device): per-device call counter +
+  // wall-clock seed, counter-based draws (kernels/extra_layers.hip)
+  static std::atomic<unsigned long long> calls[16];
+  static const unsigned long long t0 = (unsigned long long)time(nullptr);
+  const int dev = cuda_get_device();
+  const unsigned long long c = calls[dev & 15].fetch_add(1);
+  if (dk_random_uniform(x_gpu, n, (t0 << 20) ^ ((unsigned long long)dev << 56) ^ (c * 0x9E3779B97F4A7C15ULL), get_cuda_stream()))
+  {
+    fprintf(stderr, "cuda_random failed\n");
+    exit(EXIT_FAILURE);
+  }
 }
 
 DK_EXPORT dim3 cuda_gridsize(size_t n)

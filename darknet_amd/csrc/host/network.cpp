@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <map>
+#include <string>
 #include <vector>
 #include <chrono>
 #include <atomic>
@@ -1170,6 +1171,50 @@ void FreeDetections(Detection* dets, int n)
     free(dets[i].mask);
   }
   free(dets);
+}
+
+// Detection2Json (src/network.cpp:518-592; yolo_core.h:635): the JSON record the reference's server / file output
+// writes for one frame.  Same text byte for byte (printf %f fields, separators, the fixed 0.005 threshold, classes
+// whose name starts with "dont_show" skipped); built in a std::string, returned as a malloc()ed C string the
+// caller frees, like the reference's buffer.
+char* Detection2Json(Detection* dets, int nboxes, int classes, char** names, long long int frame_id, char const* filename)
+{
+  const float thresh = 0.005f;
+  std::string out;
+  char head[64];
+  snprintf(head, sizeof(head), "{\n \"frame_id\":%lld, \n", frame_id);
+  out += head;
+  if (filename)
+  {
+    out += " \"filename\":\"";
+    out += filename;
+    out += "\", \n";
+  }
+  out += " \"objects\": [ \n";
+  bool first = true;
+  for (int i = 0; i < nboxes; ++i)
+    for (int j = 0; j < classes; ++j)
+    {
+      if (!(dets[i].prob[j] > thresh) || strncmp(names[j], "dont_show", 9) == 0)
+        continue;
+      if (!first)
+        out += ", \n";
+      first = false;
+      char num[400];
+      snprintf(num, sizeof(num), "  {\"class_id\":%d, \"name\":\"", j);
+      out += num;
+      out += names[j];
+      snprintf(num, sizeof(num),
+          "\", \"relative_coordinates\":{\"center_x\":%f, \"center_y\":%f, \"width\":%f, \"height\":%f}, \"confidence\":%f}",
+          dets[i].bbox.x, dets[i].bbox.y, dets[i].bbox.w, dets[i].bbox.h, dets[i].prob[j]);
+      out += num;
+    }
+  out += "\n ] \n}";
+  char* buf = (char*)malloc(out.size() + 1);
+  if (!buf)
+    return nullptr;
+  memcpy(buf, out.c_str(), out.size() + 1);
+  return buf;
 }
 
 int DkGetBoxesBatch(Network* net, int b, float thresh, float* out, int* ids, int max_dets)

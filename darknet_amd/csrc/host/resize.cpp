@@ -174,6 +174,13 @@ void ResizeNetwork(Network* net, int w, int h)
         l->out_h = l->h = h;
         l->output_gpu = net->layers[i - 1].output_gpu;
         l->delta_gpu = net->layers[i - 1].delta_gpu;
+        // the train-mode mask is sized inputs*batch and allocated lazily by the forward slot
+        // (resize_dropout_layer, dropout_layer.c:75-76, reallocates it): drop the old one
+        if (gpu && l->rand_gpu)
+        {
+          cuda_free(l->rand_gpu);
+          l->rand_gpu = nullptr;
+        }
         break;
       case UPSAMPLE:
         l->w = w; l->h = h;
@@ -247,6 +254,12 @@ void ResizeNetwork(Network* net, int w, int h)
         DkConvPrepare(&net->layers[i]);
     net->cand_valid = 0;
     CHECK_HIP(hipStreamSynchronize(get_cuda_stream()));
+    // the device-NMS head table holds the yolo grid sizes: rebuilt on the next DkGetNetworkBoxesNms
+    if (net->nms_heads_gpu)
+    {
+      (void)hipFree(net->nms_heads_gpu);
+      net->nms_heads_gpu = nullptr;
+    }
     if (net->planned)
       DkPlanInference(net);
   }

@@ -567,12 +567,19 @@ void UpdateConvolutionalLayerGpu(layer* l, int batch, float learning_rate_init, 
         (l->scales_gpu && dk_adam_update(l->scales_gpu, l->scale_updates_gpu, l->scale_m_gpu, l->scale_v_gpu, l->B1,
                               l->B2, l->eps, decay, lr, l->n, batch, l->t, st)))
       error("dk_adam_update failed");
-    return;
   }
-  dk_sgd_update(l->weights_gpu, l->weight_updates_gpu, l->nweights, batch, lr, momentum, decay, 1, st);
-  dk_sgd_update(l->biases_gpu, l->bias_updates_gpu, l->n, batch, lr, momentum, decay, 0, st);
-  if (l->scales_gpu)
-    dk_sgd_update(l->scales_gpu, l->scale_updates_gpu, l->n, batch, lr, momentum, decay, 0, st);
+  else
+  {
+    dk_sgd_update(l->weights_gpu, l->weight_updates_gpu, l->nweights, batch, lr, momentum, decay, 1, st);
+    dk_sgd_update(l->biases_gpu, l->bias_updates_gpu, l->n, batch, lr, momentum, decay, 0, st);
+    if (l->scales_gpu)
+      dk_sgd_update(l->scales_gpu, l->scale_updates_gpu, l->n, batch, lr, momentum, decay, 0, st);
+  }
+  // convolutional_kernels.cu:919-920 (`clip=`): weights clamped to [-clip, clip] after either optimizer.  (The
+  // reference's reset_nan_and_inf / fix_nan_and_inf scrubs at :881-882 are GPU-only there and absent from the CPU path
+  // this library is pinned to; they are not reproduced: a NaN gradient stays visible instead of being zeroed.)
+  if (l->clip)
+    dk_constrain(l->nweights, l->clip, l->weights_gpu, st);
 }
 
 void BackwardMaxpoolLayerGpu(layer* l, NetworkState state)
@@ -808,8 +815,8 @@ static bool sgd_plan_usable(Network* net)
   for (int i = 0; i < net->n; ++i)
   {
     const layer* l = &net->layers[i];
-    if (l->burnin_update || l->train_only_bn || l->dont_update)
-      return false;
+    if (l->burnin_update || l->train_only_bn || l->dont_update || l->clip)
+      return false;   // (clip: the per-layer path clamps after the update)
     if (l->update_gpu && l->update_gpu != UpdateConvolutionalLayerGpu && l->update_gpu != UpdateBatchnormLayerGpu)
       return false;
   }

@@ -748,7 +748,24 @@ int dk_conv_wino_launch(ConvArgs a, int c, hipStream_t st)
   const bool pair = (a.OW % 2 == 0) && (((uintptr_t)a.y & 7) == 0) && (!a.residual || ((uintptr_t)a.residual & 7) == 0);
   WinoGeo o;
   static const bool allow16 = !(getenv("DK_WINO_VW1") && atoi(getenv("DK_WINO_VW1")));   // diagnostics: force 4-byte pieces
-  if (!wino_pick(a.W, TW, allow16 && ((uintptr_t)a.x & 3) == 0, o))
+  // 16-byte pieces straddle row ends when W is not a multiple of 4 floats, and the last piece of the tensor then
+  // reads up to 12 bytes past it.  Arrays from cuda_make_array carry 64 bytes of slack; a caller-owned tensor
+  // (dk_conv_forward on foreign memory, a plugin slot's state.input) may end at the end of its allocation, so the
+  // allocation is asked: without 16 readable bytes behind the tensor the 4-byte-piece variant runs instead.
+  bool wide_ok = allow16 && ((uintptr_t)a.x & 3) == 0;
+  if (wide_ok && (a.W & 3))
+  {
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)a.x) != hipSuccess)
+    {
+      (void)hipGetLastError();
+      wide_ok = false;
+    }
+    else
+      wide_ok = (const char*)a.x + (size_t)a.x_bytes + 16 <= (const char*)base + size;
+  }
+  if (!wino_pick(a.W, TW, wide_ok, o))
     return -1;
   a.tiles_w = TW;
   a.tiles_hw = TH * TW;

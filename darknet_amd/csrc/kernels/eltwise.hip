@@ -132,6 +132,12 @@ __global__ void scal_kernel(size_t n, float a, float* __restrict__ x)
        i += (size_t)gridDim.x * blockDim.x)
     x[i] *= a;
 }
+__global__ void constrain_kernel(size_t n, float a, float* __restrict__ x)
+{
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    x[i] = fminf(a, fmaxf(-a, x[i]));
+}
 }  // namespace
 
 extern "C" int dk_route_copy(const float* src, int input_size, int groups, int group_id, int batch,
@@ -273,6 +279,17 @@ extern "C" int dk_scal(size_t n, float alpha, float* x, void* stream)
   if (n == 0)
     return 0;
   hipLaunchKernelGGL(scal_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), n, alpha, x);
+  CHECK_HIP(hipPeekAtLastError());
+  return 0;
+}
+
+// constrain_ongpu (src/blas_kernels.cu:450-455, :874; CPU twin constrain_cpu blas.c:408): x = min(a, max(-a, x));
+// what `clip=` applies to a layer's weights after every update (convolutional_kernels.cu:919-920)
+extern "C" int dk_constrain(size_t n, float alpha, float* x, void* stream)
+{
+  if (n == 0)
+    return 0;
+  hipLaunchKernelGGL(constrain_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), n, alpha, x);
   CHECK_HIP(hipPeekAtLastError());
   return 0;
 }

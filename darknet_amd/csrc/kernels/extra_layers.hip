@@ -198,6 +198,11 @@ __global__ void dropout_forward_kernel(float* __restrict__ x, float* __restrict_
     x[i] = (r < prob) ? 0.f : x[i] * scale;
   }
 }
+__global__ void random_uniform_kernel(float* __restrict__ x, size_t n, unsigned long long seed)
+{
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    x[i] = hash_uniform(seed, i);
+}
 __global__ void dropout_backward_kernel(float* __restrict__ delta, const float* __restrict__ rnd, size_t n, float prob,
     float scale)
 {
@@ -231,6 +236,21 @@ extern "C" int dk_dropout_backward(float* delta, const float* rnd, size_t n, flo
   if (g > 65535u) g = 65535u;
   hipLaunchKernelGGL(dropout_backward_kernel, dim3(g), dim3(256), 0, stream ? (hipStream_t)stream : get_cuda_stream(), delta,
       rnd, n, probability, scale);
+  CHECK_HIP(hipPeekAtLastError());
+  return 0;
+}
+
+// Uniform [0, 1) fill of a device array: what dark_cuda.c:464-477 (`cuda_random`) gets from cuRAND, here the
+// counter-based hash of (seed, i) the dropout layer uses.
+extern "C" int dk_random_uniform(float* x, size_t n, unsigned long long seed, void* stream)
+{
+  if (n == 0)
+    return 0;
+  if (!x)
+    return 1;
+  unsigned g = (unsigned)((n + 255) / 256);
+  if (g > 65535u) g = 65535u;
+  hipLaunchKernelGGL(random_uniform_kernel, dim3(g), dim3(256), 0, stream ? (hipStream_t)stream : get_cuda_stream(), x, n, seed);
   CHECK_HIP(hipPeekAtLastError());
   return 0;
 }

@@ -4,9 +4,12 @@
  * This is the reference's src/dark_cuda.h (:56-83) re-done on HIP: same entry
  * point names, argument meaning and error behaviour (errors print and exit(),
  * src/dark_cuda.c:85-106), so host code written against dark_cuda.h relinks
- * unchanged.  No CUDA headers, no cuBLAS/cuDNN/cuRAND: `blas_handle`,
- * `cudnn_handle` and `cuda_random` are deliberately absent (nothing on the
- * conv hot path needs them once GEMM is a hand-written MFMA kernel).
+ * unchanged.  No CUDA headers, no cuBLAS/cuDNN/cuRAND: `blas_handle` and
+ * `cudnn_handle` are deliberately absent (nothing on the conv hot path needs
+ * them once GEMM is a hand-written MFMA kernel); `cuda_random` is kept, backed
+ * by a counter-based generator instead of cuRAND (same distribution, another
+ * stream: no caller can depend on cuRAND's values, the reference seeds it
+ * with time(0)).
  *
  * The only types in the signatures are plain pointers/sizes plus `hipStream_t`
  * (an opaque pointer) and `dim3`; the CUDA spellings are kept as typedefs so
@@ -66,6 +69,9 @@ DK_API void cuda_push_array(float* x_gpu, float* x, size_t n);   /* H2D on the c
 DK_API void cuda_pull_array(float* x_gpu, float* x, size_t n);   /* D2H + stream sync */
 DK_API void cuda_pull_array_async(float* x_gpu, float* x, size_t n);
 DK_API float cuda_compare(float* x_gpu, float* x, size_t n, char* s);
+/* src/dark_cuda.c:464-477: x_gpu[0..n) = uniform draws in [0, 1) on the compute stream.  The reference seeds a
+ * per-device cuRAND generator with time(0); here a per-device call counter seeds a splitmix64 hash of the index. */
+DK_API void cuda_random(float* x_gpu, size_t n);
 
 /* launch geometry helpers, src/dark_cuda.c:108-126 */
 DK_API dim3 cuda_gridsize(size_t n);

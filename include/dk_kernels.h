@@ -52,6 +52,12 @@ typedef struct DkConvDesc
  * follows).  activation_input (may be NULL) receives the pre-activation
  * value, as activate_array_mish_ongpu stores it (src/activation_kernels.cu:290).
  * No im2col buffer is materialised and no workspace is needed.
+ * Memory contract: every tensor is read and written strictly inside
+ * [ptr, ptr + its size): x, weights, y, residual may be any device pointers,
+ * no slack behind them is assumed.  (The Winograd kernel's 16-byte row pieces
+ * would read up to 12 bytes past x on feature maps whose width is not a
+ * multiple of 4; it asks the allocation -- hipMemGetAddressRange -- and takes
+ * its 4-byte-piece variant when fewer than 16 readable bytes follow x.)
  */
 DK_API int dk_conv_forward(const DkConvDesc* d, const float* x, const float* weights,
     const float* biases, float* y, const float* residual,
@@ -171,6 +177,8 @@ DK_API int dk_fill(size_t n, float alpha, float* x, void* stream);
 DK_API int dk_copy(size_t n, const float* x, float* y, void* stream);
 DK_API int dk_axpy(size_t n, float alpha, const float* x, float* y, void* stream);
 DK_API int dk_scal(size_t n, float alpha, float* x, void* stream);
+/* constrain_ongpu (blas_kernels.cu:450, :874): x = min(alpha, max(-alpha, x)) -- the `clip=` key of a layer */
+DK_API int dk_constrain(size_t n, float alpha, float* x, void* stream);
 
 /* ---- training path ------------------------------------------------------- */
 
@@ -271,6 +279,8 @@ DK_API int dk_scale_channels_backward(const float* delta, const float* in, const
 DK_API int dk_dropout_forward(float* x, float* rnd, size_t n, float probability, float scale, unsigned long long seed,
     void* stream);
 DK_API int dk_dropout_backward(float* delta, const float* rnd, size_t n, float probability, float scale, void* stream);
+/* x[0..n) = uniform draws in [0, 1): the generator behind `cuda_random` (src/dark_cuda.c:464-477) */
+DK_API int dk_random_uniform(float* x, size_t n, unsigned long long seed, void* stream);
 
 /* Profiling hooks used by bench.py (measurement only): when enabled every
  * dk_conv_forward is bracketed by HIP events on its stream; dk_profile_read

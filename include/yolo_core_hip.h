@@ -375,6 +375,9 @@ LIB_API float* NetworkPredict(Network* net, float* input);
 LIB_API Detection* GetNetworkBoxes(Network* net, float thresh, int* num);
 LIB_API Detection* MakeNetworkBoxes(Network* net, float thresh, int* num);
 LIB_API void FreeDetections(Detection* dets, int n);
+/* src/network.cpp:518-592: one frame's detections as the reference's JSON text (malloc()ed; the caller frees) */
+LIB_API char* Detection2Json(Detection* dets, int nboxes, int classes, char** names, long long int frame_id,
+    char const* filename);
 LIB_API void FuseConvBatchNorm(Network* net);
 /* src/network.cpp:255-410: new input resolution; every layer re-derives its geometry and
  * re-allocates its tensors, plans / tap tables / the captured graph are rebuilt */
@@ -612,9 +615,13 @@ typedef struct BoxLabel
 } BoxLabel;
 LIB_API std::vector<BoxLabel> ReadBoxAnnot(std::string filename);
 LIB_API std::string ReplaceImage2Label(std::string str);
+/* The reference declares these two INSIDE its extern "C" block (yolo_core.h:43-45, 640-644), so a binary built
+ * against it binds the unmangled names `TrainDetector` / `ValidateDetector`: same linkage here. */
+extern "C" {
 LIB_API float ValidateDetector(Metadata const& md, Network* net, float const iou_thresh);
 LIB_API void TrainDetector(Metadata const& md, std::string model_file, std::string weights_file, int num_gpus,
     bool clear, bool show_imgs, bool calc_map, int benchmark_layers);
+}
 /* the same with the constants of the reference exposed (thresh .005, nms .45 there) and bounded runs */
 LIB_API float DkValidateDetector(Metadata const& md, Network* net, float iou_thresh, float thresh, float nms);
 LIB_API void DkTrainDetector(Metadata const& md, std::string model_file, std::string weights_file, int num_gpus,

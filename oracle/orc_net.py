@@ -171,6 +171,7 @@ def parse_cfg(path, batch=1, train=False):
                 l.pad = l.size // 2
             l.activation = ACT_NAMES[o.get("activation", "logistic")]
             l.batch_normalize = _int(o, "batch_normalize", 0)
+            l.clip = _float(o, "clip", 0)   # src/parser.cpp:1361
             l.out_h = (h + 2 * l.pad - l.size) // l.stride_y + 1
             l.out_w = (w + 2 * l.pad - l.size) // l.stride_x + 1
             l.out_c = l.n
@@ -653,6 +654,8 @@ def update(net, actual_batch, lr, momentum, decay):
                               fptr(l.bias_updates), fptr(l.scales) if l.batch_normalize else None,
                               fptr(l.scale_updates) if l.batch_normalize else None, l.n, actual_batch,
                               F(lr), F(momentum), F(decay))
+            if getattr(l, "clip", 0):   # convolutional_kernels.cu:919-920 (GPU path only in the reference)
+                L.orc_constrain(l.nweights, F(l.clip), fptr(l.weights))
         elif l.type == BATCHNORM:
             L.orc_batchnorm_update(fptr(l.biases), fptr(l.bias_updates), fptr(l.scales), fptr(l.scale_updates),
                                    l.c, actual_batch, F(lr), F(momentum))

@@ -775,6 +775,14 @@ void orc_conv_update(float* weights, float* weight_updates, int nweights,
   }
 }
 
+/* constrain_cpu, src/blas.c:408-415 (GPU twin constrain_kernel blas_kernels.cu:450): the `clip=` clamp that
+ * UpdateConvolutionalLayerGpu applies to the weights after the update (convolutional_kernels.cu:919-920).  The
+ * reference's CPU UpdateConvolutionalLayer never calls it: the oracle applies it where the GPU path does. */
+void orc_constrain(int size, float alpha, float* x)
+{
+  for (int i = 0; i < size; ++i) x[i] = fminf(alpha, fmaxf(-alpha, x[i]));
+}
+
 /* ----------------------------------------------------------------- maxpool */
 
 /* ForwardMaxpoolLayer generic loop, src/maxpool_layer.cpp:255-297 (same

@@ -311,3 +311,52 @@ def test_dropout_train_mode(gpu, tmp_path):
     pl = onet.layers[di].probability if hasattr(onet.layers[di], "probability") else None
     assert frac > 0.05, "the dropout layer did not drop anything in train mode (zero fraction %g)" % frac
     net.close()
+
+
+def test_resize_with_dropout_in_train_mode(gpu, tmp_path):
+    """ResizeNetwork on a TRAIN-mode network with a [dropout] layer (resize_dropout_layer, dropout_layer.c:75-76,
+    reallocates the mask): one step at 32x32 allocates the mask, the resize to 64x96 must not keep it (the forward
+    would write inputs*batch draws through the old, smaller buffer).  With learning_rate=0 the weights stay put, so
+    the second step of the resized network must equal the second step of a network loaded at 64x96 from the start
+    (same iteration, same call count -> same counter-based draws): same zero pattern in the dropout output, same cost."""
+    L = gpu.lib()
+    bind(L)
+    L.ResizeNetwork.argtypes = [VP, C.c_int, C.c_int]
+    inf, _ = synth.se_cfgs(tmp_path)
+    txt = open(inf).read()
+    a = txt.index("\n[batchnorm]\n") + 1
+    txt = txt[:a] + txt[txt.index("[convolutional]", a):]
+    txt = txt.replace("batch=1", "batch=2", 1).replace("learning_rate=0.001", "learning_rate=0")
+    small, big = str(tmp_path / "d32.cfg"), str(tmp_path / "d64.cfg")
+    open(small, "w").write(txt)
+    open(big, "w").write(txt.replace("width=32", "width=64").replace("height=32", "height=96"))
+    onet = O.parse_cfg(small)
+    di = [i for i, l in enumerate(onet.layers) if l.type == O.DROPOUT][0]
+    w = str(tmp_path / "w.weights")
+    synth.write_weights_layers(w, synth.weight_layers_of(onet), seed=2024)
+    truth = np.zeros((2, 90 * 5), np.float32)
+    truth[:, :5] = (.4, .5, .3, .3, 1)
+
+    def step(net, h, wd, seed):
+        x = np.ascontiguousarray(synth.make_input(2, 3, h, wd, seed=seed))
+        net.inputs = 3 * h * wd
+        return L.TrainNetworkDatum(net.p, x.ctypes.data, truth.ctypes.data)
+
+    net = netutil.DkNet(gpu, small, w, train=True)
+    L.DkSetMaxIter(net.p, 100)
+    assert np.isfinite(step(net, 32, 32, 5))
+    L.ResizeNetwork(net.p, 64, 96)
+    c1 = step(net, 96, 64, 6)
+    o1 = net.output(di).copy()
+    net.close()
+    ref = netutil.DkNet(gpu, big, w, train=True)
+    L.DkSetMaxIter(ref.p, 100)
+    assert np.isfinite(step(ref, 96, 64, 7))
+    c2 = step(ref, 96, 64, 6)
+    o2 = ref.output(di).copy()
+    ref.close()
+    assert o1.shape == o2.shape and o1.size == 2 * 32 * 48 * 32
+    assert np.array_equal(o1 == 0, o2 == 0), "dropout mask after ResizeNetwork differs from a fresh load"
+    assert 0.2 < (o1 == 0).mean() < 0.45
+    util.assert_close(o1, o2, "dropout output after resize vs fresh load", rel=1e-4, atol_rms=3e-4)
+    assert abs(c1 - c2) <= 1e-4 * abs(c2), (c1, c2)

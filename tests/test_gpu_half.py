@@ -105,13 +105,14 @@ def test_csp_b1_half_vs_rounded_oracle(gpu, tmp_path):
     net.close()
 
 
-def test_c5_csp_512_b32_half_at_baseline_size(gpu, tmp_path):
-    """BASELINE config C5 at its full size: yolov4-csp 512x512, batch 32, fp16 operands on the 43
-    eligible layers.  Item 17's decoded heads vs the fp16-pre-rounded CPU oracle (the only possible
+@pytest.mark.parametrize("name", ["yolov4-csp", "yolov4x-mish"])
+def test_c5_csp_512_b32_half_at_baseline_size(gpu, tmp_path, name):
+    """BASELINE config C5 at its full size: yolov4-csp and yolov4x-mish 512x512, batch 32, fp16 operands on the
+    layers the reference's rule admits (43 of csp's convs).  Item 17's decoded heads vs the fp16-pre-rounded CPU oracle (the only possible
     oracle: the reference has no CPU fp16 path -- PARITY UNPINNED by construction for this row), and
     two size-independent properties at the full batch: items with identical inputs give bitwise
     identical heads wherever they sit in the batch, and the graph replay reproduces the eager run."""
-    name, B, K = "yolov4-csp", 32, 17
+    B, K = 32, 17
     wpath = str(tmp_path / "w.weights")
     netutil.synth_weights_for(gpu, name, wpath)
     L = gpu.lib()
@@ -137,7 +138,7 @@ def test_c5_csp_512_b32_half_at_baseline_size(gpu, tmp_path):
     worst = 0.0
     for i, l in enumerate(onet.layers):
         if l.type == O.YOLO:
-            st = util.assert_close(heads[i][K:K + 1], l.output, "csp b32 half head %d item %d" % (i, K), rel=2e-4, atol_rms=1e-4)
+            st = util.assert_close(heads[i][K:K + 1], l.output, "%s b32 half head %d item %d" % (name, i, K), rel=2e-4, atol_rms=1e-4)
             worst = max(worst, st["max_abs_over_rms"])
-    print("yolov4-csp 512 b32 fp16 operands: item %d heads worst max|d|/rms %.3g" % (K, worst))
+    print("%s 512 b32 fp16 operands: item %d heads worst max|d|/rms %.3g" % (name, K, worst))
     net.close()

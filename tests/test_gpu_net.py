@@ -380,6 +380,71 @@ def test_properties_at_baseline_size(gpu, weights):
     net3.close()
 
 
+def test_c3_b16_distinct_images_vs_reference_golden(gpu, weights):
+    """BASELINE config C3 (yolov4 608^2 b=16) with 16 DISTINCT images in the default plan (Winograd + direct +
+    gather kernels as tuned, fusion, graph replay): three inputs whose decoded heads and detection index lists the
+    REAL reference produced one at a time (tests/golden/net_yolov4_multi.npz, tools/make_golden.py multi) sit at
+    batch positions 0 / 7 / 15 among 13 other distinct images.  The Winograd kernel lets 16-byte DMA pieces straddle
+    row ends and its tiles straddle images: with identical images (test_properties_at_baseline_size) a read from the
+    wrong image would be invisible, here it moves a head."""
+    name, B = "yolov4", 16
+    g = np.load(os.path.join(GOLD, "net_%s_multi.npz" % name))
+    seeds = [int(s) for s in g["seeds"]]
+    pos = {0: seeds[0], 7: seeds[1], 15: seeds[2]}
+    x = np.concatenate([synth.make_input(1, 3, 608, 608, seed=pos.get(b, 5000 + b)) for b in range(B)], 0)
+    net = netutil.DkNet(gpu, netutil.cfg_path(name), weights[name], batch=B)
+    heads = [i for i in range(net.n) if net.info(i)["type"] == O.YOLO]
+    for rep in range(2):   # eager, then the captured graph
+        net.predict(x)
+        for b, sd in pos.items():
+            for i in heads:
+                util.assert_close(net.output(i)[b].ravel()[::16], g["s%d_head_%d_sub16" % (sd, i)],
+                                  "b=16 distinct images, item %d (seed %d), head %d, run %d" % (b, sd, i, rep))
+            dets, ids = net.boxes(b, float(g["s%d_thresh" % sd]))
+            assert np.array_equal(ids, g["s%d_det_ids" % sd]), "item %d: detection indices differ from the reference" % b
+            util.assert_close(dets[:, :5], g["s%d_det_box_obj" % sd], "item %d boxes" % b)
+    # the 13 filler images are distinct too: no two batch items may agree
+    h0 = net.output(heads[0])
+    assert len({h0[b].tobytes() for b in range(B)}) == B
+    net.close()
+
+
+def test_yolov4x_mish_b1_vs_reference_golden(gpu, tmp_path):
+    """BASELINE configs[4] names yolov4x-mish first: cfg/yolov4x-mish.cfg (201 layers, 139.974 BFLOPS at 512^2) in
+    fp32, b=1, shipped plan, against the real reference's run (tests/golden/net_yolov4x-mish.npz): per-layer samples
+    and checksums, decoded heads, detection index list and class ids."""
+    name = "yolov4x-mish"
+    g = np.load(os.path.join(GOLD, "net_%s.npz" % name))
+    w = str(tmp_path / "w.weights")
+    netutil.synth_weights_for(gpu, name, w)
+    assert os.path.getsize(w) == int(g["weights_bytes"])
+    net = netutil.DkNet(gpu, netutil.cfg_path(name), w)
+    assert net.n == int(g["n_layers"]) == 201
+    x = synth.make_input(1, net.c, net.h, net.w)
+    net.predict(x)
+    net.predict(x)
+    L = gpu.lib()
+    L.DkLayerFused.argtypes = [gpu.C.c_void_p, gpu.C.c_int]
+    for i in range(net.n):
+        f = net.info(i)
+        if f["type"] == O.CONVOLUTIONAL and L.DkLayerFused(net.p, i):
+            continue
+        o = net.output(i).ravel()
+        idx = np.linspace(0, o.size - 1, 64).astype(np.int64)
+        ref = g["layer_samples"][i]
+        rms = np.sqrt(g["layer_sums"][i][1] / o.size)
+        err = np.abs(o[idx] - ref) / (util.REL * np.abs(ref) + util.ATOL_RMS * rms)
+        assert err.max() <= 1.0, "%s layer %d: sample err x%.3g over tolerance" % (name, i, err.max())
+        if f["type"] == O.YOLO:
+            util.assert_close(o[::16], g["head_%d_sub16" % i], "%s head %d" % (name, i))
+    dets, ids = net.boxes(0, float(g["thresh"]))
+    assert len(dets) == int(g["num_dets"])
+    assert np.array_equal(ids, g["det_ids"]), name + ": detection indices differ from the reference"
+    assert np.array_equal(np.argmax(dets[:, 5:], 1), g["det_best_class"]), name + ": class ids differ"
+    util.assert_close(dets[:, :5], g["det_box_obj"], name + " boxes")
+    net.close()
+
+
 @pytest.mark.parametrize("wino", [0, 1])
 def test_resize_network_vs_oracle(gpu, tmp_path, wino):
     """ResizeNetwork (src/network.cpp:255-410): yolov4-tiny loaded at 416x416 (batch 2, planned
@@ -424,6 +489,57 @@ def test_resize_network_vs_oracle(gpu, tmp_path, wino):
             assert np.array_equal(net.output(i), h0), "416x416 after resizing there and back differs"
     net.close()
     L.DkSetWinograd(1)
+
+
+def test_resize_then_device_nms_equals_fresh_load(gpu, tmp_path):
+    """ResizeNetwork must drop the device-NMS head table (yolo grid sizes + anchors, built on first use): after a
+    resize DkGetBoxesBatchNms has to decode with the NEW grid.  yolov4-tiny: device NMS at 416x416 (builds the table),
+    resize to 320x352, device NMS again == a fresh load at 320x352, bitwise (winograd off: both plans then hold only
+    the k-ascending kernels)."""
+    name = "yolov4-tiny"
+    L = gpu.lib()
+    L.ResizeNetwork.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.DkSetPullHeads.argtypes = [C.c_int]
+    L.DkSetWinograd.argtypes = [C.c_int]
+    L.DkSetWinograd.restype = None
+    L.DkGetBoxesBatchNms.restype = C.c_int
+    L.DkGetBoxesBatchNms.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int]
+    w = str(tmp_path / "w.weights")
+    netutil.synth_weights_for(gpu, name, w)
+    nw, nh = 320, 352
+    cfg = str(tmp_path / "r.cfg")
+    open(cfg, "w").write(open(netutil.cfg_path(name)).read().replace("width=416", "width=%d" % nw).replace("height=416", "height=%d" % nh))
+    g = np.load(os.path.join(GOLD, "net_%s.npz" % name))
+    thresh = float(g["thresh"]) * 0.5
+
+    def nms_boxes(net, x):
+        net.predict(x)
+        classes = net.info(net.n - 1)["classes"]
+        cap = 100000
+        buf = np.zeros((cap, 5 + classes), np.float32)
+        ids = np.zeros((cap, 4), np.int32)
+        n = L.DkGetBoxesBatchNms(net.p, 0, thresh, 0.45, buf.ctypes.data, ids.ctypes.data, cap)
+        assert 0 < n < cap
+        return buf[:n].copy(), ids[:n].copy()
+
+    L.DkSetWinograd(0)
+    L.DkSetPullHeads(0)
+    try:
+        net = netutil.DkNet(gpu, netutil.cfg_path(name), w)
+        nms_boxes(net, synth.make_input(1, 3, 416, 416))        # builds the 416x416 head table
+        L.ResizeNetwork(net.p, nw, nh)
+        net.inputs = 3 * nw * nh
+        x = synth.make_input(1, 3, nh, nw, seed=5)
+        d1, i1 = nms_boxes(net, x)
+        net.close()
+        fresh = netutil.DkNet(gpu, cfg, w)
+        d2, i2 = nms_boxes(fresh, x)
+        fresh.close()
+    finally:
+        L.DkSetPullHeads(1)
+        L.DkSetWinograd(1)
+    assert np.array_equal(i1, i2) and np.array_equal(d1, d2), "device NMS after ResizeNetwork differs from a fresh load"
+    assert i1[:, 2].max() < nh // 16 + 1 and i1[:, 3].max() < nw // 16 + 1
 
 
 @pytest.mark.parametrize("name", ["yolov4-tiny", "yolov4-csp"])

@@ -405,3 +405,61 @@ def test_conv_winograd_vs_oracle(gpu, case):
     for cfg in wino:
         # variants: 16- or 4-byte row pieces x paired or single stores; a launch that fell back books none of them
         assert sum(out[(cfg * 4 + v) * 3] for v in range(4)) == 1, "config %s did not launch" % names[cfg]
+
+
+def test_conv_winograd_on_caller_owned_memory_without_slack(gpu):
+    """dk_conv_forward's memory contract (include/dk_kernels.h): no bytes behind a tensor are assumed readable.
+    The Winograd kernel's 16-byte row pieces straddle row ends on maps whose width is not a multiple of 4 and would
+    read up to 12 bytes past the input; library arrays (cuda_make_array) carry slack, a caller's hipMalloc does not.
+    Input placed so that it ENDS at the end of a raw hipMalloc allocation: the launch must take the 4-byte-piece
+    variant (profile slots 2 / 3) and still match the oracle; the same input in a library array takes the 16-byte
+    variant (slots 0 / 1)."""
+    batch, c, h, w, n = 2, 32, 38, 38, 64
+    act = O.LEAKY
+    rng = np.random.default_rng(11)
+    x = rng.uniform(-1, 1, (batch, c, h, w)).astype(np.float32)
+    wt = (rng.uniform(-1, 1, (n, c, 3, 3)) * np.sqrt(2.0 / (9 * c))).astype(np.float32)
+    bias = rng.uniform(-.5, .5, n).astype(np.float32)
+    ref, _ = orc_conv(x, wt, bias, batch, c, h, w, n, 3, 1, 1, act)
+    L = gpu.lib()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    hip.hipMemGetAddressRange.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p]
+    raw = C.c_void_p()
+    lead = 4096                               # the tensor sits at the END of the allocation
+    assert hip.hipMalloc(C.byref(raw), lead + x.nbytes) == 0
+    xptr = raw.value + lead
+    base, size = C.c_void_p(), C.c_size_t()
+    assert hip.hipMemGetAddressRange(C.byref(base), C.byref(size), C.c_void_p(xptr)) == 0
+    if base.value + size.value != xptr + x.nbytes:
+        hip.hipFree(raw)
+        pytest.skip("hipMemGetAddressRange reports a padded allocation (%d bytes for %d): no way to place a tensor at "
+                    "the end of one" % (size.value, lead + x.nbytes))
+    assert hip.hipMemcpy(C.c_void_p(xptr), x.ctypes.data, x.nbytes, 1) == 0
+    d = gpu.DkConvDesc(batch, c, h, w, n, 1, 3, 1, 1, 1, 1, act)
+    dw, db, dy = gpu.DeviceArray(wt), gpu.DeviceArray(bias), gpu.DeviceArray(n=batch * n * h * w)
+    du = gpu.DeviceArray(n=L.dk_conv_wino_weights_size(C.byref(d)))
+    assert L.dk_conv_wino_transform_weights(C.byref(d), dw.ptr, du.ptr, None) == 0
+    L.dk_conv_wino_register(dw.ptr, du.ptr)
+    ncfg = L.dk_conv_force_config(-1)
+    names = [L.dk_conv_config_name(i).decode() for i in range(ncfg)]
+    cfg = [i for i, nm in enumerate(names) if nm.startswith("wino")][0]
+    dx = gpu.DeviceArray(x)
+    try:
+        L.dk_conv_force_config(cfg)
+        for ptr, want in ((xptr, (2, 3)), (dx.ptr, (0, 1))):
+            L.dk_profile_enable(1)
+            assert L.dk_conv_forward(C.byref(d), C.c_void_p(ptr), dw.ptr, db.ptr, dy.ptr, None, None, None) == 0
+            y = dy.numpy().reshape(ref.shape)
+            out = (C.c_double * (3 * 256))()
+            L.dk_profile_read(out, 256)
+            L.dk_profile_enable(0)
+            ran = [v for v in range(4) if out[(cfg * 4 + v) * 3] == 1]
+            assert len(ran) == 1 and ran[0] in want, "variant %s ran, expected one of %s" % (ran, want)
+            util.assert_close(y, ref, "winograd on %s memory" % ("caller-owned" if ptr == xptr else "library"))
+    finally:
+        L.dk_conv_force_config(-1)
+        L.dk_conv_wino_register(dw.ptr, None)
+        hip.hipFree(raw)

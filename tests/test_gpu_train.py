@@ -942,3 +942,66 @@ def test_adam_update_vs_oracle(gpu, tmp_path):
         util.assert_close(pull(i, 1, w0.size), w1, "adam net step, conv %d weights" % i, rel=2e-6, atol_rms=1e-7)
         assert not pull(i, 7, w0.size).any()
     net.close()
+
+
+def test_clip_clamps_weights_after_the_update(gpu, tmp_path):
+    """`clip=` (parser.cpp:1361; applied by UpdateConvolutionalLayerGpu, convolutional_kernels.cu:919-920, through
+    constrain_ongpu blas_kernels.cu:450): dk_constrain bitwise vs the oracle's constrain_cpu restatement, and one
+    deterministic yolov4-tiny train step with clip=0.02 on two layers == clamp(the same step without clip), bitwise,
+    while unclipped layers are untouched.  (The reference's CPU update never clips -- this line follows its GPU path;
+    the arithmetic itself is fminf / fmaxf.)"""
+    L = gpu.lib()
+    L.dk_constrain.argtypes = [C.c_size_t, C.c_float, VP, VP]
+    rng = np.random.default_rng(0)
+    v = (rng.normal(0, 0.05, 100003)).astype(np.float32)
+    v[:3] = (0.02, -0.02, np.float32(0.020000001))
+    dv = gpu.DeviceArray(v)
+    assert L.dk_constrain(v.size, 0.02, dv.ptr, None) == 0
+    want = v.copy()
+    O.lib().orc_constrain(want.size, O.F(0.02), O.fptr(want))
+    assert np.array_equal(dv.numpy(), want) and np.abs(want).max() == np.float32(0.02)
+
+    g, cfg, wpath, x = train_fixture(tmp_path)
+    for fn, at, rt in (("TrainNetworkDatum", [VP, VP, VP], C.c_float), ("DkSetMaxIter", [VP, C.c_int], None),
+                       ("DkSetDeterministic", [C.c_int], None),
+                       ("DkLayerPull", [VP, C.c_int, C.c_int, VP, C.c_size_t], C.c_long)):
+        getattr(L, fn).argtypes = at
+        getattr(L, fn).restype = rt
+    txt = open(cfg).read()
+    secs = txt.split("[convolutional]")
+    clipped = (1, 4)   # conv sections (1-based pieces of the split): conv layers 0 and 3
+    for k in clipped:
+        secs[k] = "\nclip=0.02" + secs[k]
+    ccfg = str(tmp_path / "clip.cfg")
+    open(ccfg, "w").write("[convolutional]".join(secs))
+    onet = O.parse_cfg(ccfg)
+    conv_ids = [i for i, l in enumerate(onet.layers) if l.type == O.CONVOLUTIONAL]
+    clip_layers = [conv_ids[k - 1] for k in clipped]
+    assert [onet.layers[i].clip for i in clip_layers] == [0.02, 0.02]
+    truth = np.ascontiguousarray(g["truth"])
+    xin = np.ascontiguousarray(x)
+
+    def run(c):
+        net = netutil.DkNet(gpu, c, wpath, train=True)
+        L.DkSetMaxIter(net.p, 1000)
+        cost = L.TrainNetworkDatum(net.p, xin.ctypes.data, truth.ctypes.data)
+        ws = {}
+        for i in conv_ids[:6]:
+            n = net.info(i)["nweights"]
+            ws[i] = np.empty(n, np.float32)
+            assert L.DkLayerPull(net.p, i, 1, ws[i].ctypes.data, n) == n
+        net.close()
+        return cost, ws
+    L.DkSetDeterministic(1)
+    try:
+        c0, w0 = run(cfg)
+        c1, w1 = run(ccfg)
+    finally:
+        L.DkSetDeterministic(0)
+    assert c0 == c1
+    for i in conv_ids[:6]:
+        if i in clip_layers:
+            assert np.abs(w0[i]).max() > 0.02, "the fixture's weights never reach the clip value"
+            assert np.array_equal(w1[i], np.clip(w0[i], np.float32(-0.02), np.float32(0.02))), "layer %d" % i
+        else:
+            assert np.array_equal(w1[i], w0[i]), "unclipped layer %d changed" % i

@@ -293,3 +293,30 @@ def test_learning_rate_schedules_vs_reference_golden(dk, tmp_path):
         bad = np.nonzero(got.view(np.uint32) != ref.view(np.uint32))[0]
         assert bad.size == 0, (pol, [(MG.LR_ITERS[i], float(got[i]), float(ref[i])) for i in bad[:5]])
         L.DkNetworkDestroy(p)
+
+
+def test_detection2json_vs_reference_golden(dk):
+    """Detection2Json (src/network.cpp:518-592, yolo_core.h:635): byte-identical text to the reference's own
+    function (fixture tests/golden/detection2json.npz, generated by tools/make_golden.py json from
+    oracle/_ref): %f fields, separators, the fixed 0.005 threshold, `dont_show*` classes skipped, with / without a
+    file name, empty list; and against the live reference library where it exists."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_golden as MG
+    import reflib
+    g = np.load(os.path.join(GOLD, "detection2json.npz"))
+    L = dk.lib()
+    box, prob, names = MG.json_case()
+    assert np.array_equal(box, g["box"]) and np.array_equal(prob, g["prob"])
+    a = MG.call_detection2json(L, box, prob, names, 42, b"data/frame 17.jpg")
+    b = MG.call_detection2json(L, box, prob, names, 9876543210123, None)
+    e = MG.call_detection2json(L, box[:0], prob[:0], names, 0, None)
+    assert a == g["with_name"].tobytes()
+    assert b == g["without_name"].tobytes()
+    assert e == g["empty"].tobytes()
+    assert b"dont_show" not in a and a.count(b"class_id") == 8
+    if reflib.available():
+        R = reflib.lib()
+        rng = np.random.default_rng(3)
+        box2 = rng.uniform(0, 1, (40, 4)).astype(np.float32)
+        prob2 = rng.uniform(0, 0.02, (40, 5)).astype(np.float32)
+        assert MG.call_detection2json(L, box2, prob2, names, 1, b"x") == MG.call_detection2json(R, box2, prob2, names, 1, b"x")

@@ -762,8 +762,109 @@ def gen_lr():
     np.savez_compressed(os.path.join(GOLD, "lr_schedule.npz"), **out)
 
 
+class DetStruct(C.Structure):
+    """Detection (src/box.h:68-85)"""
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("w", C.c_float), ("h", C.c_float), ("classes", C.c_int),
+                ("prob", FP), ("mask", FP), ("objectness", C.c_float), ("sort_class", C.c_int), ("uc", FP),
+                ("points", C.c_int)]
+
+
+def json_case():
+    """Synthetic detections for Detection2Json: 7 boxes x 5 classes, a `dont_show` class, values around the fixed
+    0.005 threshold, one box with nothing above it."""
+    rng = np.random.default_rng(7)
+    n, classes = 7, 5
+    box = rng.uniform(0.05, 0.95, (n, 4)).astype(np.float32)
+    prob = rng.uniform(0, 1, (n, classes)).astype(np.float32)
+    prob[prob < 0.55] = 0
+    prob[1, 2] = np.float32(0.005)      # not above the threshold
+    prob[2, 0] = np.float32(0.0050001)
+    prob[3, :] = 0
+    prob[4, 3] = np.float32(0.75)       # class 3 is dont_show
+    names = [b"person", b"traffic light", b"dog", b"dont_show_me", b"kite"]
+    return box, prob, names
+
+
+def call_detection2json(L, box, prob, names, frame_id, filename):
+    n, classes = prob.shape
+    arr = (DetStruct * n)()
+    keep = []
+    for i in range(n):
+        pr = np.ascontiguousarray(prob[i])
+        keep.append(pr)
+        arr[i].x, arr[i].y, arr[i].w, arr[i].h = [float(v) for v in box[i]]
+        arr[i].classes = classes
+        arr[i].prob = pr.ctypes.data_as(FP)
+    nm = (C.c_char_p * classes)(*names)
+    L.Detection2Json.restype = C.c_void_p
+    L.Detection2Json.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.c_longlong, C.c_char_p]
+    ptr = L.Detection2Json(arr, n, classes, nm, frame_id, filename)
+    txt = C.string_at(ptr)
+    C.CDLL(None).free(C.c_void_p(ptr))
+    return txt
+
+
+def gen_json():
+    """detection2json.npz: the reference's Detection2Json (src/network.cpp:518-592) on json_case(), with and
+    without a file name."""
+    L = reflib.lib()
+    box, prob, names = json_case()
+    a = call_detection2json(L, box, prob, names, 42, b"data/frame 17.jpg")
+    b = call_detection2json(L, box, prob, names, 9876543210123, None)
+    e = call_detection2json(L, box[:0], prob[:0], names, 0, None)
+    np.savez_compressed(os.path.join(GOLD, "detection2json.npz"), box=box, prob=prob,
+                        with_name=np.frombuffer(a, np.uint8), without_name=np.frombuffer(b, np.uint8),
+                        empty=np.frombuffer(e, np.uint8))
+    print(a.decode())
+
+
+def gen_net_multi(name="yolov4", seeds=(101, 202, 303)):
+    """net_<cfg>_multi.npz: the reference's decoded heads (1/16 subsample) and detection ids for several more
+    inputs of the same weights (b = 1 each) -- the batched HIP run places them at different batch positions among
+    other distinct images (tests/test_gpu_net.py), which is what catches a tile reading the wrong image."""
+    cfg = os.path.join(ROOT, "cfg", name + ".cfg")
+    net = O.parse_cfg(cfg)
+    convs = [(l.n, l.c // l.groups, l.size, l.batch_normalize) for l in net.layers if l.type == O.CONVOLUTIONAL]
+    wpath = f"/tmp/_dk_{name}.weights"
+    synth.write_weights(wpath, convs, seed=2024)
+    rn = reflib.RefNet(cfg, wpath, train=False)
+    out = {"seeds": np.array(seeds, np.int32)}
+    for sd in seeds:
+        x = synth.make_input(1, net.c, net.h, net.w, seed=sd)
+        rn.predict(x)
+        allobj = []
+        for i in range(rn.n):
+            inf = rn.info(i)
+            if inf["type"] != O.YOLO:
+                continue
+            o = rn.output(i)
+            out[f"s{sd}_head_{i}_sub16"] = o[::16].copy()
+            wh = inf["out_h"] * inf["out_w"]
+            v = o.reshape(3, 5 + inf["classes"], wh)
+            allobj.append(v[:, 4, :].ravel())
+            allobj.append((v[:, 4:5, :] * v[:, 5:, :]).ravel())
+        thresh = pick_threshold(np.concatenate(allobj))
+        dets = rn.boxes(thresh)
+        onet = O.load_network(cfg, wpath, batch=1)
+        O.forward(onet, x)
+        od, oid = O.get_boxes(onet, thresh)
+        assert np.array_equal(od, dets), "oracle and reference detections differ"
+        out[f"s{sd}_thresh"] = np.float32(thresh)
+        out[f"s{sd}_det_ids"] = oid
+        out[f"s{sd}_det_box_obj"] = dets[:, :5].copy()
+        print(f"{name} seed {sd}: {len(dets)} dets at {thresh:.6f}")
+    rn.close()
+    np.savez_compressed(os.path.join(GOLD, f"net_{name}_multi.npz"), **out)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "lr":
+    if len(sys.argv) > 1 and sys.argv[1] == "json":
+        gen_json()
+    elif len(sys.argv) > 1 and sys.argv[1] == "multi":
+        gen_net_multi(sys.argv[2] if len(sys.argv) > 2 else "yolov4")
+    elif len(sys.argv) > 1 and sys.argv[1] == "net":
+        gen_net(sys.argv[2], len(sys.argv) > 3 and sys.argv[3] == "full")
+    elif len(sys.argv) > 1 and sys.argv[1] == "lr":
         gen_lr()
     elif len(sys.argv) > 1 and sys.argv[1] == "map":
         gen_map()
