@@ -963,7 +963,8 @@ def test_clip_clamps_weights_after_the_update(gpu, tmp_path):
 
     g, cfg, wpath, x = train_fixture(tmp_path)
     for fn, at, rt in (("TrainNetworkDatum", [VP, VP, VP], C.c_float), ("DkSetMaxIter", [VP, C.c_int], None),
-                       ("DkSetDeterministic", [C.c_int], None),
+                       ("DkSetDeterministic", [C.c_int], None), ("UpdateNetworkGpu", [VP], None),
+                       ("DkAdvanceIteration", [VP], None),
                        ("DkLayerPull", [VP, C.c_int, C.c_int, VP, C.c_size_t], C.c_long)):
         getattr(L, fn).argtypes = at
         getattr(L, fn).restype = rt
@@ -985,6 +986,8 @@ def test_clip_clamps_weights_after_the_update(gpu, tmp_path):
         net = netutil.DkNet(gpu, c, wpath, train=True)
         L.DkSetMaxIter(net.p, 1000)
         cost = L.TrainNetworkDatum(net.p, xin.ctypes.data, truth.ctypes.data)
+        L.DkAdvanceIteration(net.p)     # TrainNetwork (network.cpp:210-236): curr_iter++ and then the update
+        L.UpdateNetworkGpu(net.p)
         ws = {}
         for i in conv_ids[:6]:
             n = net.info(i)["nweights"]
@@ -1005,3 +1008,5 @@ def test_clip_clamps_weights_after_the_update(gpu, tmp_path):
             assert np.array_equal(w1[i], np.clip(w0[i], np.float32(-0.02), np.float32(0.02))), "layer %d" % i
         else:
             assert np.array_equal(w1[i], w0[i]), "unclipped layer %d changed" % i
+    init = np.fromfile(wpath, np.float32)
+    assert not np.isin(w0[conv_ids[0]][:8], init).all(), "the update did not run"
