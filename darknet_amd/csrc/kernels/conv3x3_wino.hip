@@ -85,7 +85,6 @@ constexpr int WCK = 4;               // input channels per stage
 constexpr int W_STAGE = 16 * 64 * WCK;  // floats of one operand's stage image (16 KB)
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f32x16 mfma2(float a, float b, f32x16 c)
@@ -365,32 +364,27 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& p, f32x16 (&acc)[8
     emit(std::integral_constant<int, -1>());
 }
 
-// SCHED selects the K loop's schedule (all variants compute the same sums in the same order):
+// SCHED selects the K loop's schedule (both compute the same sums in the same order):
 //   0  every wave reads the 16 operand fragments of a stage behind the stage's barrier, then issues its 16 MFMAs;
 //      the LDS-DMA waves issue their pieces in one burst behind the barrier (round 2)
 //   1  software-pipelined across the barrier: a stage's second half (positions 4-7 of the wave) is multiplied BEHIND
 //      the next barrier, from fragments read before it, while the first half's fragments of the new stage are in
-//      flight -- no wave waits for LDS right behind a barrier any more
-//   2  = 1 with the LDS-DMA pieces spread between the MFMAs instead of issued in a burst
-//   3  = 1 with COMPLEMENTARY phases for the two waves of a SIMD: the transform waves (0-3) run the whole input
-//      transform of the next stage first and multiply afterwards, the LDS-DMA waves (4-7) multiply first and issue their
-//      pieces afterwards -- while one wave of a SIMD is busy with its non-matrix work the other owns the matrix pipe.
-//      (Stamped build, [128->128 76x76]: a stage takes 3 950 cycles against 2 048 of MFMA; the DMA waves spend 1 160 of
-//      them issuing ten pieces BEFORE their MFMAs while the transform waves' MFMAs are strung out behind LDS waits.)
-//   4  = 0 with the transformed FILTERS read straight from L2 into the MFMA operand registers (one stage ahead, double
-//      buffered) instead of LDS-DMA -> LDS ring -> ds_read: per stage that takes 16 KB of LDS-DMA writes and 32 KB of
-//      fragment reads off the LDS (of ~127 KB) and 4 of a DMA wave's ~10 pieces; the freed 48 KB deepen the raw ring
+//      flight -- no wave waits for LDS right behind a barrier.  Within 1-3 % of schedule 0 on every shape; the tuner
+//      picks it for the short-K layers (C = 32 / 64).
+// Round 3 also measured, and dropped (`git log` for the code): the LDS-DMA pieces spread between the
+// MFMAs; complementary phases for the two waves of a SIMD (transform first / multiply first); s_setprio for either
+// half; a symmetric kernel in which every wave issues a share of the pieces and transforms half of V, the halves
+// staggered by half a stage (10-18 % SLOWER); the filters read from L2 straight into the operand registers instead of
+// through the LDS ring (11-18 % slower).  None beat schedule 0.
 template <int VW, bool PAIR, int SCHED>
 __global__ void __launch_bounds__(512) conv3x3_wino_f32(const ConvArgs p)
 {
   constexpr int KMAX = wino_kmax(VW);
-  constexpr bool UREG = SCHED == 4;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int D = p.wino_ring;             // ring depth (3 or 4: what fits the 160 KB), prefetch distance D - 1 stages
-  const int UD = UREG ? 0 : D;                 // slots of the filter ring (schedule 4: none)
-  float* const Us = lds;                       // [UD][W_STAGE] transformed filters, LDS-DMA ring
-  float* const Vs = lds + UD * W_STAGE;        // [2][W_STAGE]  transformed input, double-buffered
-  float* const Rs = lds + (UD + 2) * W_STAGE;  // [D][RAWF]     raw input rows, LDS-DMA ring: [4 ch][RS rows][Pw]
+  float* const Us = lds;                       // [D][W_STAGE]  transformed filters, LDS-DMA ring
+  float* const Vs = lds + D * W_STAGE;         // [2][W_STAGE]  transformed input, double-buffered
+  float* const Rs = lds + (D + 2) * W_STAGE;   // [D][RAWF]     raw input rows, LDS-DMA ring: [4 ch][RS rows][Pw]
 
   int g, tile_m, tile_n;
   if (!conv_block_tile(p, g, tile_m, tile_n))
@@ -422,7 +416,7 @@ __global__ void __launch_bounds__(512) conv3x3_wino_f32(const ConvArgs p)
   const u32x4_t ur = make_rsrc(p.w, p.w_bytes);
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)lds);
   const unsigned u_lds = lds0 + (unsigned)(wq * 64) * 16u;                               // + slot * 16 KB + j * 4 KB
-  const unsigned r_lds = lds0 + (unsigned)((UD + 2) * W_STAGE) * 4u + (unsigned)(wq * 64 * VW) * 4u;   // + slot * RAWF * 4 + k * 256 * VW * 4
+  const unsigned r_lds = lds0 + (unsigned)((D + 2) * W_STAGE) * 4u + (unsigned)(wq * 64 * VW) * 4u;   // + slot * RAWF * 4 + k * 256 * VW * 4
 
   // ---- geometry of the strip: tile rows R0 .. Rlast (R = b * TH + ty), first tile column tx0 ----
   const int R0 = fdiv(n0, TW, p.inv_tiles_w);
@@ -509,33 +503,11 @@ __global__ void __launch_bounds__(512) conv3x3_wino_f32(const ConvArgs p)
     const unsigned dst = u_lds + (unsigned)((s % D) * W_STAGE) * 4u;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      if (!(DK_WABL & 2) && !UREG)
+      if (!(DK_WABL & 2))
         dma16(ur, dst + (unsigned)j * 4096u, uo + (unsigned)j * 4096u);
   };
-  // one piece of bundle B(s) (SCHED 2): q < 4 filters, q >= 4 raw rows
-  auto issue_piece = [&](int s, int q) {
-    if (q < 4)
-    {
-      if (s < nst && !(DK_WABL & 2))
-        dma16(ur, u_lds + (unsigned)((s % D) * W_STAGE) * 4u + (unsigned)q * 4096u,
-            ubase + (unsigned)s * (unsigned)(W_STAGE * 4) + (unsigned)q * 4096u);
-    }
-    else
-    {
-      const int k = q - 4;
-      if (s + 1 < nst && k < NK && !(DK_WABL & 1))
-      {
-        const unsigned xo = (unsigned)(s + 1) * stage_x_bytes;
-        const unsigned dst = r_lds + (unsigned)(((s + 1) % D) * RAWF) * 4u;
-        if constexpr (VW == 4)
-          dma16(xr, dst + (unsigned)k * 4096u, xoff[k < KMAX ? k : 0] + xo);
-        else
-          dma4(xr, dst + (unsigned)k * 1024u, xoff[k < KMAX ? k : 0] + xo);
-      }
-    }
-  };
   // bundle B(s) = {filters of stage s, raw rows of stage s + 1}: both are first needed in iteration s
-  const int cnt_u = ((DK_WABL & 2) || UREG) ? 0 : 4, cnt_r = (DK_WABL & 1) ? 0 : NK;
+  const int cnt_u = (DK_WABL & 2) ? 0 : 4, cnt_r = (DK_WABL & 1) ? 0 : NK;
   auto bundle_count = [&](int s) { return (s < nst ? cnt_u : 0) + (s + 1 < nst ? cnt_r : 0); };
   auto issue_bundle = [&](int s) {
     if (s < nst)
@@ -596,28 +568,6 @@ __global__ void __launch_bounds__(512) conv3x3_wino_f32(const ConvArgs p)
     }
   };
 
-  // ---- schedule 4: this lane's filter operands of a stage = 8 x 8 bytes of the slab (position rows 2 xh, 2 xh + 1, the
-  // wave's 32 filters, channel pair lh), loaded by inline asm (form (ii) of cdna_hip_programming.md 5.7: hipcc must not
-  // count them, its waits would drain the LDS-DMA ring) into `fn`, one stage ahead; `fnwait` makes them opaque behind
-  // the counted wait that covers them.  Issue order per wave and stage: filter loads, THEN the LDS-DMA bundle, so that
-  // the counted wait at the top of the next stage (bundle(s) it leaves in flight) implies the filter loads.
-  f32x2_t fn[8];
-  const unsigned ureg_base = (unsigned)(tile_m * nst) * (unsigned)(W_STAGE * 4) + (unsigned)(xh * 8192 + wm * 512 + lh * 256 + l31 * 8);
-  auto issue_ureg = [&](int s) {
-    if (UREG && s < nst)
-    {
-      const unsigned v0 = ureg_base + (unsigned)s * (unsigned)(W_STAGE * 4), v1 = v0 + 4096u;
-#define DK_ULOAD(I, V, OFF) asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen offset:" #OFF : "=v"(fn[I]) : "v"(V), "s"(ur) : "memory")
-      DK_ULOAD(0, v0, 0); DK_ULOAD(1, v0, 1024); DK_ULOAD(2, v0, 2048); DK_ULOAD(3, v0, 3072);
-      DK_ULOAD(4, v1, 0); DK_ULOAD(5, v1, 1024); DK_ULOAD(6, v1, 2048); DK_ULOAD(7, v1, 3072);
-#undef DK_ULOAD
-    }
-  };
-  auto fnwait = [&]() {
-    asm volatile("" : "+v"(fn[0]), "+v"(fn[1]), "+v"(fn[2]), "+v"(fn[3]), "+v"(fn[4]), "+v"(fn[5]), "+v"(fn[6]), "+v"(fn[7]));
-  };
-  issue_ureg(0);
-
   // ---- prologue: raw(0), B(0) .. B(D-2) in flight; V(0) from raw(0) ----------------------------
   if (dma_wave)
   {
@@ -643,58 +593,7 @@ __global__ void __launch_bounds__(512) conv3x3_wino_f32(const ConvArgs p)
     tslice(std::integral_constant<int, 7>(), Rs, Vs);
   }
 
-  if constexpr (SCHED == 4)
-  {
-    for (int t = 0; t < nst; ++t)
-    {
-      // every wave: the filter loads of stage t (issued a stage ago, BEFORE that stage's bundle B(t + D - 2)) have landed;
-      // DMA waves: only that youngest bundle may still be in flight, so B(t) has landed too
-      if (dma_wave)
-        wait_vmcnt_n(bundle_count(t + D - 2));
-      else
-        wait_vmcnt_n(0);
-      fnwait();
-      barrier_lds();
-      float2 fa[2][4], fb[2][4];
-#pragma unroll
-      for (int gq = 0; gq < 2; ++gq)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) fa[gq][u] = make_float2(fn[gq * 4 + u].x, fn[gq * 4 + u].y);
-      issue_ureg(t + 1);
-      if (dma_wave)
-        issue_bundle(t + D - 1);
-      const float2* const Va = (const float2*)(Vs + (t & 1) * W_STAGE) + (xh * 8) * 128 + wn * 64 + lh * 32 + l31;
-      const float* const Rcur = Rs + ((t + 1) % D) * RAWF;
-      float* const Vnext = Vs + ((t + 1) & 1) * W_STAGE;
-#pragma unroll
-      for (int gq = 0; gq < 2; ++gq)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) fb[gq][u] = Va[(gq * 4 + u) * 128];
-      auto group = [&](auto gc) {
-        constexpr int grp = decltype(gc)::value;
-        DK_WINO_SB;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc[grp * 4 + u] = mfma2(fa[grp][u].x, fb[grp][u].x, acc[grp * 4 + u]);
-        if (xf_wave)
-        {
-          tslice(std::integral_constant<int, grp * 4 + 0>(), Rcur, Vnext);
-          tslice(std::integral_constant<int, grp * 4 + 1>(), Rcur, Vnext);
-        }
-        DK_WINO_SB;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc[grp * 4 + u] = mfma2(fa[grp][u].y, fb[grp][u].y, acc[grp * 4 + u]);
-        if (xf_wave)
-        {
-          tslice(std::integral_constant<int, grp * 4 + 2>(), Rcur, Vnext);
-          tslice(std::integral_constant<int, grp * 4 + 3>(), Rcur, Vnext);
-        }
-        DK_WINO_SB;
-      };
-      group(std::integral_constant<int, 0>());
-      group(std::integral_constant<int, 1>());
-    }
-  }
-  else if constexpr (SCHED == 0)
+  if constexpr (SCHED == 0)
   {
     for (int t = 0; t < nst; ++t)
     {
@@ -757,21 +656,13 @@ __global__ void __launch_bounds__(512) conv3x3_wino_f32(const ConvArgs p)
     //   before the barrier) -> request group 0 of stage t -> MFMAs of group 1 of stage t - 1 (no LDS wait: the
     //   fragments are in registers) -> request group 1 of stage t -> MFMAs of group 0 of stage t.
     float2 fa[2][4], fb[2][4];
-    constexpr bool SPREAD = SCHED == 2 && VW == 4;   // (4-byte pieces: up to 22 per bundle, more than the 16 MFMA slots)
-    auto block = [&](auto gc, auto sc0, auto withx, auto pc0, int sb, const float* Rcur, float* Vnext) {
+    auto block = [&](auto gc, auto sc0, auto withx, const float* Rcur, float* Vnext) {
       constexpr int grp = decltype(gc)::value;      // register group multiplied here
       constexpr int s0 = decltype(sc0)::value;      // first of the four transform slices placed here
       constexpr bool XF = decltype(withx)::value;   // place transform slices (false: the drain block)
-      constexpr int q0 = decltype(pc0)::value;      // first LDS-DMA piece placed here (SCHED 2), -1: none
       DK_WINO_SB;
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-      {
-        acc[grp * 4 + u] = mfma2(fa[grp][u].x, fb[grp][u].x, acc[grp * 4 + u]);
-        if constexpr (SPREAD && q0 >= 0)
-          if (dma_wave)
-            issue_piece(sb, q0 + u);
-      }
+      for (int u = 0; u < 4; ++u) acc[grp * 4 + u] = mfma2(fa[grp][u].x, fb[grp][u].x, acc[grp * 4 + u]);
       if constexpr (XF)
         if (xf_wave)
         {
@@ -780,13 +671,7 @@ __global__ void __launch_bounds__(512) conv3x3_wino_f32(const ConvArgs p)
         }
       DK_WINO_SB;
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-      {
-        acc[grp * 4 + u] = mfma2(fa[grp][u].y, fb[grp][u].y, acc[grp * 4 + u]);
-        if constexpr (SPREAD && q0 >= 0)
-          if (dma_wave && q0 + 4 + u < 4 + KMAX)
-            issue_piece(sb, q0 + 4 + u);
-      }
+      for (int u = 0; u < 4; ++u) acc[grp * 4 + u] = mfma2(fa[grp][u].y, fb[grp][u].y, acc[grp * 4 + u]);
       if constexpr (XF)
         if (xf_wave)
         {
@@ -804,9 +689,8 @@ __global__ void __launch_bounds__(512) conv3x3_wino_f32(const ConvArgs p)
       WSTAMP(9 + 4 * t);
       barrier_lds();
       WSTAMP(10 + 4 * t);
-      if constexpr (!SPREAD && SCHED != 3)
-        if (dma_wave)
-          issue_bundle(t + D - 1);
+      if (dma_wave)
+        issue_bundle(t + D - 1);
       const float2* const Ua = (const float2*)(Us + (t % D) * W_STAGE) + (xh * 8) * 128 + wm * 64 + lh * 32 + l31;
       const float2* const Va = (const float2*)(Vs + (t & 1) * W_STAGE) + (xh * 8) * 128 + wn * 64 + lh * 32 + l31;
       const float* const Rcur = Rs + ((t + 1) % D) * RAWF;
@@ -817,47 +701,11 @@ __global__ void __launch_bounds__(512) conv3x3_wino_f32(const ConvArgs p)
         fa[0][u] = Ua[u * 128];
         fb[0][u] = Va[u * 128];
       }
-      if constexpr (SCHED == 3)
-      {
-        if (xf_wave)
-        {
-          tslice(integral_constant<int, 0>(), Rcur, Vnext);
-          tslice(integral_constant<int, 1>(), Rcur, Vnext);
-          tslice(integral_constant<int, 2>(), Rcur, Vnext);
-          tslice(integral_constant<int, 3>(), Rcur, Vnext);
-          tslice(integral_constant<int, 4>(), Rcur, Vnext);
-          tslice(integral_constant<int, 5>(), Rcur, Vnext);
-          tslice(integral_constant<int, 6>(), Rcur, Vnext);
-          tslice(integral_constant<int, 7>(), Rcur, Vnext);
-        }
-        if (t > 0)
-          block(integral_constant<int, 1>(), integral_constant<int, 0>(), std::false_type(), integral_constant<int, -1>(),
-              0, Rcur, Vnext);
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-        {
-          fa[1][u] = Ua[(4 + u) * 128];
-          fb[1][u] = Va[(4 + u) * 128];
-        }
-        block(integral_constant<int, 0>(), integral_constant<int, 4>(), std::false_type(), integral_constant<int, -1>(), 0,
-            Rcur, Vnext);
-        WSTAMP(11 + 4 * t);   // MFMAs issued (transform waves: their transform too)
-        if (dma_wave)
-          issue_bundle(t + D - 1);
-        continue;
-      }
       if (t > 0)
-        block(integral_constant<int, 1>(), integral_constant<int, 0>(), std::true_type(), integral_constant<int, 0>(),
-            t + D - 1, Rcur, Vnext);
+        block(integral_constant<int, 1>(), integral_constant<int, 0>(), std::true_type(), Rcur, Vnext);
       else
       {
-        // nothing to multiply yet: only the first half of the next stage's input transform (and the pieces)
-        if constexpr (SPREAD)
-          if (dma_wave)
-          {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) issue_piece(t + D - 1, q);
-          }
+        // nothing to multiply yet: only the first half of the next stage's input transform
         if (xf_wave)
         {
           tslice(integral_constant<int, 0>(), Rcur, Vnext);
@@ -872,13 +720,10 @@ __global__ void __launch_bounds__(512) conv3x3_wino_f32(const ConvArgs p)
         fa[1][u] = Ua[(4 + u) * 128];
         fb[1][u] = Va[(4 + u) * 128];
       }
-      // (SCHED 2: pieces 0-7 went with the first block, the last raw pieces 8, 9 go here)
-      block(integral_constant<int, 0>(), integral_constant<int, 4>(), std::true_type(), integral_constant<int, 8>(),
-          t + D - 1, Rcur, Vnext);
+      block(integral_constant<int, 0>(), integral_constant<int, 4>(), std::true_type(), Rcur, Vnext);
     }
     // drain: group 1 of the last stage
-    block(integral_constant<int, 1>(), integral_constant<int, 0>(), std::false_type(), integral_constant<int, -1>(), 0,
-        nullptr, nullptr);
+    block(integral_constant<int, 1>(), integral_constant<int, 0>(), std::false_type(), nullptr, nullptr);
   }
 
   wino_epilogue<PAIR>(p, acc, lds, m0, n0, wave, lane);
@@ -887,245 +732,6 @@ __global__ void __launch_bounds__(512) conv3x3_wino_f32(const ConvArgs p)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
   WSTAMP(7);
-}
-
-// =====================================================================================================================
-// conv3x3_wino2_f32 -- the same decomposition, tile, LDS images and arithmetic (bitwise the same result) with SYMMETRIC
-// waves and STAGGERED phases (round 3).  What the stamped builds of the kernel above showed on [128->128 76x76]
-// (tools/wino_stamps.py, s_memtime at the phase boundaries): a stage takes ~3 400 cycles where its 32 MFMAs per SIMD need
-// 2 048; with the LDS-DMA and the input transform compiled out it still takes ~2 450 (two waves of a SIMD alternate at
-// ~70 cycles per MFMA, plus the barrier), the LDS-DMA adds ~800 and the transform ~400 -- because the ROLES are lopsided:
-// a wave of 4-7 spends ~90-120 cycles of issue time on each of its ten LDS-DMA pieces per stage, a wave of 0-3 ~1 700
-// cycles on the latency-bound chain raw rows -> B^T d B -> V writes, each longer than the ~1 100 cycles its SIMD partner
-// needs for its 16 MFMAs, so the partner cannot cover it, and re-ordering the phases inside the roles (schedules 1-3)
-// moved nothing.  Here every wave does the same work per stage -- 16 MFMAs, five LDS-DMA pieces, HALF of the input
-// transform (waves 0-3 produce the position rows 0-1 of V, waves 4-7 the rows 2-3) -- and the two waves of a SIMD run
-// it in opposite order: waves 0-3 multiply first and then issue / transform, waves 4-7 issue / transform first and then
-// multiply, so the matrix pipe always has one owner while the other wave does its ~1 000 cycles of other work.
-// 16-byte row pieces only (launches whose geometry needs 4-byte pieces take the kernel above).
-// =====================================================================================================================
-constexpr int W2_KMAX = 3;   // raw LDS-DMA pieces per thread and stage (512 threads enumerate the patch)
-
-template <bool PAIR>
-__global__ void __launch_bounds__(512) conv3x3_wino2_f32(const ConvArgs p)
-{
-  constexpr int VW = 4;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int D = 3;
-  float* const Us = lds;                       // [D][W_STAGE]
-  float* const Vs = lds + D * W_STAGE;         // [2][W_STAGE]
-  float* const Rs = lds + (D + 2) * W_STAGE;   // [D][RAWF]
-
-  int g, tile_m, tile_n;
-  if (!conv_block_tile(p, g, tile_m, tile_n))
-    return;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, lh = lane >> 5;
-  const int xh = wave >> 2, wq = wave & 3;     // xh: position rows 2 xh, 2 xh + 1 (MFMA) AND V rows produced (transform)
-  const int wm = wq & 1, wn = wq >> 1;
-  const bool first = xh == 0;                  // waves 0-3 multiply first, waves 4-7 last
-  const int m0 = tile_m * WBM, n0 = tile_n * WBN;
-  const int nst = p.C / WCK;
-  const int TW = p.tiles_w, TH = p.wino_th;
-  const int GP = p.wino_gp, RS = p.wino_rs, NK = p.wino_nk;   // NK: pieces per thread with 512 threads enumerating
-  const int Pw = VW * GP;
-  const int RAWF = NK * 512 * VW;
-
-  const u32x4_t xr = make_rsrc(p.x, p.x_bytes + 16u);   // (the host checked that 16 bytes behind x are readable)
-  const u32x4_t ur = make_rsrc(p.w, p.w_bytes);
-  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)lds);
-  const unsigned u_lds = lds0 + (unsigned)(wave * 64) * 16u;                                    // + slot * 16 KB + j * 8 KB
-  const unsigned r_lds = lds0 + (unsigned)((D + 2) * W_STAGE) * 4u + (unsigned)(wave * 64 * VW) * 4u;   // + slot * RAWF * 4 + k * 8 KB
-
-  const int R0 = fdiv(n0, TW, p.inv_tiles_w);
-  const int tx0 = n0 - R0 * TW;
-  const int nlast = (n0 + WBN - 1 < p.N) ? n0 + WBN - 1 : p.N - 1;
-  const int Rlast = fdiv(nlast, TW, p.inv_tiles_w);
-  const bool wide = TW > WBN;
-  auto g0_of = [&](int r) { const int txs = (wide && r == 0) ? tx0 : 0; return (2 * txs - 1 + VW) / VW - 1; };
-
-  // raw patch pieces: element e = tid + 512 * k is column group gg of row (c, r, i) -- same patch image as the kernel above
-  unsigned xoff[W2_KMAX];
-#pragma unroll
-  for (int k = 0; k < W2_KMAX; ++k)
-  {
-    const int e = tid + 512 * k;
-    const int c = fdiv(e, RS * GP, p.inv_wino_rsg);
-    const int rem = e - c * RS * GP;
-    const int rowi = fdiv(rem, GP, p.inv_wino_gp);
-    const int gg = rem - rowi * GP;
-    const int r = rowi >> 2, i = rowi & 3;
-    const int R = R0 + r;
-    const int b = fdiv(R, TH, p.inv_wino_th);
-    const int ty = R - b * TH;
-    const int iy = 2 * ty - 1 + i;
-    const int col0 = VW * (g0_of(r) + gg);
-    const bool ok = k < NK && c < WCK && R <= Rlast && iy >= 0 && iy < p.H && col0 > -VW && col0 < p.W;
-    xoff[k] = ok ? (unsigned)(((b * p.Ctot + c) * p.H + iy) * p.W + col0) * 4u : OOB;
-  }
-
-  // input-transform ownership: (channel, tile) per thread of a 256-thread half as above; this half's V rows are 2 xh, 2 xh + 1
-  const int c4 = (lane & 1) + 2 * lh;
-  int rsrc, vdst;
-  unsigned cmask = 0;
-  {
-    const int tl = wq * 16 + ((lane >> 1) & 15);
-    const int n = (n0 + tl < p.N) ? n0 + tl : nlast;
-    const int R = fdiv(n, TW, p.inv_tiles_w);
-    const int tx = n - R * TW;
-    const int r = R - R0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if ((unsigned)(2 * tx - 1 + j) >= (unsigned)p.W)
-        cmask |= 1u << j;
-    // first raw row this half reads: rows 0, 1, 2 (V rows 0, 1) or 1, 2, 3 (V rows 2, 3)
-    rsrc = (c4 * RS + 4 * r + xh) * Pw + 2 * tx - 1 - VW * g0_of(r);
-    vdst = img_off(8 * xh, tl >> 5, tl & 31, c4);
-  }
-  const unsigned stage_x_bytes = (unsigned)(WCK * p.H * p.W) * 4u;
-  const unsigned ubase = (unsigned)(tile_m * nst) * (unsigned)(W_STAGE * 4) + (unsigned)tid * 16u;
-
-  f32x16 acc[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-
-  // LDS-DMA issue, every wave its share: filters of stage s = 16 pieces of 1 KB, wave w takes pieces w and w + 8;
-  // raw rows of stage s: NK pieces per thread
-  auto issue_u = [&](int s) {
-    if (s < nst)
-    {
-      const unsigned uo = ubase + (unsigned)s * (unsigned)(W_STAGE * 4);
-      const unsigned dst = u_lds + (unsigned)((s % D) * W_STAGE) * 4u;
-      dma16(ur, dst, uo);
-      dma16(ur, dst + 8192u, uo + 8192u);
-    }
-  };
-  auto issue_raw = [&](int s) {
-    if (s < nst)
-    {
-      const unsigned xo = (unsigned)s * stage_x_bytes;
-      const unsigned dst = r_lds + (unsigned)((s % D) * RAWF) * 4u;
-#pragma unroll
-      for (int k = 0; k < W2_KMAX; ++k)
-        if (k < NK)
-          dma16(xr, dst + (unsigned)k * 8192u, xoff[k] + xo);
-    }
-  };
-  // bundle B(s) = {filters of stage s, raw rows of stage s + 1}
-  auto bundle_count = [&](int s) { return (s < nst ? 2 : 0) + (s + 1 < nst ? NK : 0); };
-  auto issue_bundle = [&](int s) {
-    issue_u(s);
-    issue_raw(s + 1);
-  };
-
-  // this half's two rows of V = B^T d B for the thread's (channel, tile): raw rows q = 0, 1, 2 counted from the half's
-  // first row; the column pass (d B) first, then the two row combinations -- the operation order of the kernel above
-  auto transform = [&](const float* Rcur, float* Vnext) {
-    float ww[3][4];
-#pragma unroll
-    for (int q = 0; q < 3; ++q)
-    {
-      const float* const src = Rcur + rsrc + q * Pw;
-      const float d0 = src[0];
-      const float2 mid = *(const float2*)(src + 1);
-      const float d3 = src[3];
-      const float e0 = (cmask & 1u) ? 0.f : d0;
-      const float e1 = (cmask & 2u) ? 0.f : mid.x;
-      const float e2 = (cmask & 4u) ? 0.f : mid.y;
-      const float e3 = (cmask & 8u) ? 0.f : d3;
-      ww[q][0] = e0 - e2;
-      ww[q][1] = e1 + e2;
-      ww[q][2] = e2 - e1;
-      ww[q][3] = e1 - e3;
-    }
-    float* const dst = Vnext + vdst;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-    {
-      // xh = 0: V row 0 = w0 - w2, row 1 = w1 + w2 (raw rows 0, 1, 2);  xh = 1: V row 2 = w2 - w1, row 3 = w1 - w3 of
-      // the full patch = (this half's rows 1, 0) and (0, 2)
-      const float va = first ? ww[0][j] - ww[2][j] : ww[1][j] - ww[0][j];
-      const float vb = first ? ww[1][j] + ww[2][j] : ww[0][j] - ww[2][j];
-      dst[j * 256] = va;
-      dst[(4 + j) * 256] = vb;
-    }
-  };
-
-  // zero the raw ring once (padding positions are never written again); the filters of the first stages do not depend
-  // on it and go first
-  issue_u(0);
-  issue_u(1);
-  for (int i = tid * 4; i < D * RAWF; i += 2048) *(float4*)(Rs + i) = make_float4(0.f, 0.f, 0.f, 0.f);
-  barrier_lds();
-  issue_raw(0);
-  issue_raw(1);
-  issue_raw(2);
-  // in flight, oldest first: U(0) U(1) raw(0) raw(1) raw(2); raw(0) is needed now
-  wait_vmcnt_n((1 < nst ? NK : 0) + (2 < nst ? NK : 0));
-  barrier_lds();
-  transform(Rs, Vs);
-
-  float2 fa[2][4], fb[2][4];
-  auto mfma_group = [&](auto gc) {
-    constexpr int grp = decltype(gc)::value;
-    DK_WINO_SB;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) acc[grp * 4 + u] = mfma2(fa[grp][u].x, fb[grp][u].x, acc[grp * 4 + u]);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) acc[grp * 4 + u] = mfma2(fa[grp][u].y, fb[grp][u].y, acc[grp * 4 + u]);
-    DK_WINO_SB;
-  };
-  using std::integral_constant;
-  for (int t = 0; t < nst; ++t)
-  {
-    // own pieces of U(t) and raw(t + 1) have landed; behind the barrier everybody's, and V(t) is complete.  In flight
-    // afterwards (D = 3): U(t + 1), raw(t + 2) -- except in the first iteration, where the prologue's order leaves only
-    // raw(2) behind the pieces needed now
-    wait_vmcnt_n(t == 0 ? (2 < nst ? NK : 0) : bundle_count(t + 1));
-    barrier_lds();
-    const float2* const Ua = (const float2*)(Us + (t % D) * W_STAGE) + (xh * 8) * 128 + wm * 64 + lh * 32 + l31;
-    const float2* const Va = (const float2*)(Vs + (t & 1) * W_STAGE) + (xh * 8) * 128 + wn * 64 + lh * 32 + l31;
-    const float* const Rcur = Rs + ((t + 1) % D) * RAWF;
-    float* const Vnext = Vs + ((t + 1) & 1) * W_STAGE;
-    // bundle issued in this iteration: U(t + 2) and raw(t + 3); the prologue already sent raw(1), raw(2), U(0), U(1)
-    if (!first)
-    {
-      issue_u(t + 2);
-      issue_raw(t + 3);
-      if (t + 1 < nst)
-        transform(Rcur, Vnext);
-    }
-    DK_WINO_SB;
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-    {
-      fa[0][u] = Ua[u * 128];
-      fb[0][u] = Va[u * 128];
-    }
-    if (t > 0)
-      mfma_group(integral_constant<int, 1>());
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-    {
-      fa[1][u] = Ua[(4 + u) * 128];
-      fb[1][u] = Va[(4 + u) * 128];
-    }
-    mfma_group(integral_constant<int, 0>());
-    if (first)
-    {
-      issue_u(t + 2);
-      issue_raw(t + 3);
-      if (t + 1 < nst)
-        transform(Rcur, Vnext);
-    }
-  }
-  mfma_group(integral_constant<int, 1>());   // drain: second half of the last stage
-
-  wino_epilogue<PAIR>(p, acc, lds, m0, n0, wave, lane);
 }
 
 // U = G g G^T of one (filter m, channel c) with taps g[9], written in the kernel's slab order
@@ -1301,28 +907,23 @@ bool wino_pick(int W, int TW, bool allow16, WinoGeo& o)
 }
 
 // configurations = K-loop schedules of the one 64 x 64 tile shape (template SCHED)
-int dk_conv_wino_num_configs() { return 6; }
+int dk_conv_wino_num_configs() { return 2; }
 const char* dk_conv_wino_config_name(int c)
 {
-  static const char* names[6] = {"wino_64x64", "wino_64x64_pipe", "wino_64x64_pipe_spread", "wino_64x64_pipe_compl",
-      "wino2_64x64", "wino_64x64_ureg"};
-  return (c >= 0 && c < 6) ? names[c] : nullptr;
+  static const char* names[2] = {"wino_64x64", "wino_64x64_pipe"};
+  return (c >= 0 && c < 2) ? names[c] : nullptr;
 }
 const char* dk_conv_wino_kernel_name(int c, int variant)
 {
-  static const char* names[6][4] = {
+  static const char* names[2][4] = {
       {"conv3x3_wino_f32<4, true, 0>", "conv3x3_wino_f32<4, false, 0>", "conv3x3_wino_f32<1, true, 0>", "conv3x3_wino_f32<1, false, 0>"},
-      {"conv3x3_wino_f32<4, true, 1>", "conv3x3_wino_f32<4, false, 1>", "conv3x3_wino_f32<1, true, 0>", "conv3x3_wino_f32<1, false, 0>"},
-      {"conv3x3_wino_f32<4, true, 2>", "conv3x3_wino_f32<4, false, 2>", "conv3x3_wino_f32<1, true, 0>", "conv3x3_wino_f32<1, false, 0>"},
-      {"conv3x3_wino_f32<4, true, 3>", "conv3x3_wino_f32<4, false, 3>", "conv3x3_wino_f32<1, true, 0>", "conv3x3_wino_f32<1, false, 0>"},
-      {"conv3x3_wino2_f32<true>", "conv3x3_wino2_f32<false>", "conv3x3_wino_f32<1, true, 0>", "conv3x3_wino_f32<1, false, 0>"},
-      {"conv3x3_wino_f32<4, true, 4>", "conv3x3_wino_f32<4, false, 4>", "conv3x3_wino_f32<1, true, 0>", "conv3x3_wino_f32<1, false, 0>"}};
-  return (c >= 0 && c < 6 && variant >= 0 && variant < 4) ? names[c][variant] : nullptr;
+      {"conv3x3_wino_f32<4, true, 1>", "conv3x3_wino_f32<4, false, 1>", "conv3x3_wino_f32<1, true, 0>", "conv3x3_wino_f32<1, false, 0>"}};
+  return (c >= 0 && c < 2 && variant >= 0 && variant < 4) ? names[c][variant] : nullptr;
 }
 bool dk_conv_wino_applicable(const DkConvDesc* d, int c)
 {
   WinoGeo o;
-  return c >= 0 && c < 6 && shape_ok(d) && wino_pick(d->w, (d->w + 1) / 2, true, o);
+  return c >= 0 && c < 2 && shape_ok(d) && wino_pick(d->w, (d->w + 1) / 2, true, o);
 }
 
 const float* dk_conv_wino_lookup(const float* weights)
@@ -1404,41 +1005,8 @@ int dk_conv_wino_launch(ConvArgs a, int c, hipStream_t st)
     if (force == 4 && (6 * W_STAGE + 4 * raw_f) * (int)sizeof(float) <= 160 * 1024)
       a.wino_ring = 4;
   }
-  if (c == 4 && o.vw == 4)
-  {
-    // symmetric kernel: 512 threads enumerate the raw patch (same image, pieces per thread halved and rounded up)
-    const int nk2 = (WCK * o.rs * o.gp + 511) / 512;
-    const int bytes2 = (5 * W_STAGE + 3 * nk2 * 512 * 4) * (int)sizeof(float);
-    if (nk2 <= W2_KMAX && bytes2 <= 160 * 1024)
-    {
-      a.wino_nk = nk2;
-      a.wino_ring = 3;
-      void (*k2)(const ConvArgs) = pair ? conv3x3_wino2_f32<true> : conv3x3_wino2_f32<false>;
-      dk_set_max_dynamic_lds((const void*)k2, bytes2);
-      hipLaunchKernelGGL(k2, dim3((unsigned)nblk), dim3(512), bytes2, st, a);
-      return pair ? 0 : 1;
-    }
-    c = 0;   // (does not fit: the asymmetric kernel, schedule 0)
-  }
-  else if (c == 4)
-    c = 0;
-  int bytes = ((a.wino_ring + 2) * W_STAGE + a.wino_ring * raw_f) * (int)sizeof(float);
-  if (c == 5 && o.vw == 4)
-  {
-    // filters through registers: no filter ring (a deeper raw ring would buy nothing: the counted wait that covers the
-    // filter loads of a stage also covers every older bundle); the epilogue's exchange needs 64 KB whatever the rings take
-    a.wino_ring = 3;
-    bytes = (2 * W_STAGE + a.wino_ring * raw_f) * (int)sizeof(float);
-    if (bytes < 64 * 1024)
-      bytes = 64 * 1024;
-  }
-  else if (c == 5)
-    c = 0;
-  void (*k)(const ConvArgs) = c == 5   ? wino_kernel_of<4>(o.vw, pair)
-                              : c == 3 ? wino_kernel_of<3>(o.vw, pair)
-                              : c == 2 ? wino_kernel_of<2>(o.vw, pair)
-                              : c == 1 ? wino_kernel_of<1>(o.vw, pair)
-                                       : wino_kernel_of<0>(o.vw, pair);
+  const int bytes = ((a.wino_ring + 2) * W_STAGE + a.wino_ring * raw_f) * (int)sizeof(float);
+  void (*k)(const ConvArgs) = c == 1 ? wino_kernel_of<1>(o.vw, pair) : wino_kernel_of<0>(o.vw, pair);
   dk_set_max_dynamic_lds((const void*)k, bytes);
   hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(512), bytes, st, a);
   return (o.vw == 4 ? 0 : 2) + (pair ? 0 : 1);
