@@ -134,8 +134,15 @@ DK_EXPORT void show_cuda_cudnn_info(void)
       prop.totalGlobalMem / (1024.0 * 1024.0 * 1024.0));
 }
 
+// Replicas of a data-parallel run that share a device (a test rig: two replica threads on one GPU through the real
+// collective path) each get their own compute stream: the thread's override wins over the per-device stream.
+static thread_local cudaStream_t t_stream_override = nullptr;
+DK_EXPORT void dk_set_thread_stream(cudaStream_t s) { t_stream_override = s; }
+
 DK_EXPORT cudaStream_t get_cuda_stream(void)
 {
+  if (t_stream_override)
+    return t_stream_override;
   int i = cuda_get_device();
   if (i < 0 || i >= kMaxDevices)
   {

@@ -149,12 +149,18 @@ void load_rccl()
 {
   if (g_rccl.h)
     return;
-  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
-  for (const char* n : names)
-    if ((g_rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL)))
+  // DK_RCCL_LIB: another library with the same six entry points (tests/shim_rccl.c: host-staged sums, so that the
+  // thread-per-replica / segment / stream-ordering code below runs on a box with ONE GPU)
+  const char* override_lib = getenv("DK_RCCL_LIB");
+  const char* names[] = {override_lib ? override_lib : "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  for (int k = 0; k < (override_lib ? 1 : 3); ++k)
+    if ((g_rccl.h = dlopen(names[k], RTLD_NOW | RTLD_GLOBAL)))
       break;
   if (!g_rccl.h)
-    error("TrainNetworks: cannot load librccl.so (multi-GPU training needs RCCL)");
+  {
+    fprintf(stderr, "TrainNetworks: dlopen(%s): %s\n", names[0], dlerror());
+    error("TrainNetworks: cannot load the collective library (multi-GPU training needs RCCL)");
+  }
   auto sym = [](const char* s) {
     void* p = dlsym(g_rccl.h, s);
     if (!p)
@@ -190,6 +196,7 @@ struct DpState
   bool rccl = false;            // distinct devices -> RCCL; replicas sharing one device -> local sum
   ncclComm_t comm = nullptr;
   hipStream_t cs = nullptr;     // communication stream
+  hipStream_t own = nullptr;    // compute stream of a replica that shares its device with another one (collective mode)
   std::vector<hipEvent_t> seg_ready;
   hipEvent_t comm_done = nullptr;
   float* bucket = nullptr;
@@ -221,8 +228,13 @@ void dp_setup(Network* nets, int n)
     for (int j = 0; j < i; ++j)
       if (nets[i].gpu_index == nets[j].gpu_index)
         distinct = false;
+  // Replicas on ONE device normally take the serial local-sum path.  With DK_DP_SHARED_DEVICE_COLLECTIVE=1 (test rigs,
+  // together with DK_RCCL_LIB) they run as on distinct devices -- one host thread each, the collective library between
+  // them -- on compute streams and reduction scratch of their own.
+  const bool shared_collective = !distinct && getenv("DK_DP_SHARED_DEVICE_COLLECTIVE") && atoi(getenv("DK_DP_SHARED_DEVICE_COLLECTIVE"));
+  const bool collective = n > 1 && (distinct || shared_collective);
   std::vector<ncclComm_t> comms(n, nullptr);
-  if (n > 1 && distinct)
+  if (collective)
   {
     load_rccl();
     std::vector<int> devs(n);
@@ -243,8 +255,10 @@ void dp_setup(Network* nets, int n)
     }
     st->world = n;
     st->rank = i;
-    st->rccl = n > 1 && distinct;
+    st->rccl = collective;
     st->comm = comms[i];
+    if (shared_collective && !st->own)
+      CHECK_HIP(hipStreamCreateWithFlags(&st->own, hipStreamNonBlocking));
     if (!st->cs)
       CHECK_HIP(hipStreamCreateWithFlags(&st->cs, hipStreamNonBlocking));
     if (!st->comm_done)
@@ -276,10 +290,27 @@ void dp_setup(Network* nets, int n)
 
 // forward/backward of one replica over its subdivisions; on the last subdivision the bucket
 // slices go to RCCL as the backward pass finalises them
+// the calling thread's compute stream for the lifetime of the guard (replicas sharing a device)
+struct ThreadStream
+{
+  explicit ThreadStream(hipStream_t s) : on(s != nullptr)
+  {
+    if (on)
+      dk_set_thread_stream(s);
+  }
+  ~ThreadStream()
+  {
+    if (on)
+      dk_set_thread_stream(nullptr);
+  }
+  bool on;
+};
+
 float replica_step(Network* net, data d)
 {
   cuda_set_device(net->gpu_index);
   DpState* st = (DpState*)net->dp;
+  ThreadStream ts(st->own);
   hipStream_t s = get_cuda_stream();
   const int batch = net->batch, subdiv = net->subdiv;
   if (d.X.rows != batch * subdiv)
@@ -321,6 +352,7 @@ void DkFreeDpState(Network* net)
   for (auto e : st->seg_ready) (void)hipEventDestroy(e);
   if (st->comm_done) (void)hipEventDestroy(st->comm_done);
   if (st->cs) (void)hipStreamDestroy(st->cs);
+  if (st->own) (void)hipStreamDestroy(st->own);
   if (st->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(st->comm);
   if (st->bucket && st->bucket == net->grad_bucket)
   {
@@ -397,6 +429,7 @@ float TrainNetworks(Network* nets, int num_gpus, data d, int sync_interval)
   {
     auto upd = [&](int i) {
       cuda_set_device(nets[i].gpu_index);
+      ThreadStream ts(((DpState*)nets[i].dp)->own);
       nets[i].curr_iter++;
       UpdateNetworkGpu(&nets[i]);
       CHECK_HIP(hipStreamSynchronize(get_cuda_stream()));
@@ -432,6 +465,15 @@ void SyncNetworks(Network* nets, int num_gpus)
   const float inv = 1.0f / num_gpus;
   auto tensors = [](layer* l, std::vector<std::pair<float*, size_t>>& v) {
     v.clear();
+    if (l->type == BATCHNORM)
+    {
+      // standalone [batchnorm]: its gradients ride in the bucket, so its parameters are replicated state too
+      v.push_back({l->biases_gpu, (size_t)l->c});
+      v.push_back({l->scales_gpu, (size_t)l->c});
+      v.push_back({l->rolling_mean_gpu, (size_t)l->c});
+      v.push_back({l->rolling_variance_gpu, (size_t)l->c});
+      return;
+    }
     if (l->type != CONVOLUTIONAL)
       return;
     v.push_back({l->biases_gpu, (size_t)l->n});
@@ -451,6 +493,7 @@ void SyncNetworks(Network* nets, int num_gpus)
         Network* net = &nets[i];
         cuda_set_device(net->gpu_index);
         DpState* st = (DpState*)net->dp;
+        ThreadStream ts(st->own);
         hipStream_t s = get_cuda_stream();
         std::vector<std::pair<float*, size_t>> v;
         for (int j = 0; j < net->n; ++j)

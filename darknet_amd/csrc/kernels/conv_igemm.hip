@@ -737,6 +737,7 @@ bool dk_conv_config_applicable(const DkConvDesc* d, int cfg)
 }
 
 bool dk_conv_config_is_wino(int cfg) { return cfg >= wino_base() && cfg < total_cfgs(); }
+extern "C" int dk_conv_config_can_run(const DkConvDesc* d, int cfg) { return d && dk_conv_config_applicable(d, cfg) ? 1 : 0; }
 
 extern "C" int dk_conv_pick_config(const DkConvDesc* d)
 {

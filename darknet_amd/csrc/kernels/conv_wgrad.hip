@@ -17,6 +17,10 @@
 // kernel's branch-free gather (per-stage padding mask of the thread's pixel,
 // out-of-range flag ORed into the byte offset, hardware bounds check).
 #include <hip/hip_runtime.h>
+
+#include <map>
+#include <mutex>
+#include <utility>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -367,49 +371,56 @@ __global__ void wgrad_fold_kernel(float* __restrict__ ws, float* __restrict__ dw
 }
 
 // per-device workspace of the tap-major path (stream-ordered use: one suffices), grown on demand, zero on creation
+namespace
+{
+struct WsBuf { float* p = nullptr; size_t cap = 0; };
+std::mutex g_ws_mu;
+int ws_device()
+{
+  int dev = 0;
+  CHECK_HIP(hipGetDevice(&dev));
+  return dev;
+}
+}  // namespace
+
+// (both workspaces are keyed by device AND stream: the weight gradients of replicas that share a device run on
+// different streams and must not share a workspace)
 float* wgrad_workspace(size_t floats, hipStream_t st)
 {
-  static float* buf[64] = {nullptr};
-  static size_t cap[64] = {0};
-  int dev = 0;
-  CHECK_HIP(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 64)
-    dev = 0;
-  if (cap[dev] < floats)
+  static std::map<std::pair<int, void*>, WsBuf> bufs;
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  WsBuf& b = bufs[{ws_device(), (void*)st}];
+  if (b.cap < floats)
   {
-    if (buf[dev])
+    if (b.p)
     {
       CHECK_HIP(hipStreamSynchronize(st));
-      CHECK_HIP(hipFree(buf[dev]));
+      CHECK_HIP(hipFree(b.p));
     }
-    CHECK_HIP(hipMalloc((void**)&buf[dev], floats * sizeof(float)));
-    CHECK_HIP(hipMemsetAsync(buf[dev], 0, floats * sizeof(float), st));
-    cap[dev] = floats;
+    CHECK_HIP(hipMalloc((void**)&b.p, floats * sizeof(float)));
+    CHECK_HIP(hipMemsetAsync(b.p, 0, floats * sizeof(float), st));
+    b.cap = floats;
   }
-  return buf[dev];
+  return b.p;
 }
 
-// partial-tile workspace of the deterministic form (per device, grown on demand; contents never assumed)
+// partial-tile workspace of the deterministic form (grown on demand; contents never assumed)
 float* wgrad_part_workspace(size_t floats, hipStream_t st)
 {
-  static float* buf[64] = {nullptr};
-  static size_t cap[64] = {0};
-  int dev = 0;
-  CHECK_HIP(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 64)
-    dev = 0;
-  if (cap[dev] < floats)
+  static std::map<std::pair<int, void*>, WsBuf> bufs;
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  WsBuf& b = bufs[{ws_device(), (void*)st}];
+  if (b.cap < floats)
   {
-    if (buf[dev])
+    if (b.p)
     {
-      CHECK_HIP(hipDeviceSynchronize());
-      CHECK_HIP(hipFree(buf[dev]));
+      CHECK_HIP(hipStreamSynchronize(st));
+      CHECK_HIP(hipFree(b.p));
     }
-    CHECK_HIP(hipMalloc((void**)&buf[dev], floats * sizeof(float)));
-    cap[dev] = floats;
+    CHECK_HIP(hipMalloc((void**)&b.p, floats * sizeof(float)));
+    b.cap = floats;
   }
-  (void)st;
-  return buf[dev];
+  return b.p;
 }
 
 typedef void (*WgradKernel)(const WgradArgs);
@@ -435,6 +446,30 @@ bool dk_deterministic()
 {
   static const bool env_on = getenv("DK_DETERMINISTIC") && atoi(getenv("DK_DETERMINISTIC"));
   return g_deterministic >= 0 ? g_deterministic != 0 : env_on;
+}
+
+// Variant knobs of the weight gradient, settable in-process (tests force every variant; the environment variables
+// DK_WGRAD_TILE / DK_WGRAD_TMAJ remain as defaults read once): tile shape 0..3 (-1: by the layer), tap-major tiles
+// (-1 / 1: where applicable, 0: never), 16-byte delta loads (-1: where the layout allows, 0: never).
+static int g_force_tile = -2, g_force_tmaj = -2, g_force_avec = -2;
+extern "C" int dk_train_force(int knob, int value)
+{
+  int* k = knob == 0 ? &g_force_tile : knob == 1 ? &g_force_tmaj : knob == 2 ? &g_force_avec : nullptr;
+  if (!k)
+    return -3;
+  const int old = *k;
+  *k = value < 0 ? -2 : value;
+  return old == -2 ? -1 : old;
+}
+static int wgrad_knob_tile()
+{
+  static const int env = getenv("DK_WGRAD_TILE") ? atoi(getenv("DK_WGRAD_TILE")) : 0;   // 1..3: OR-ed into the choice
+  return g_force_tile != -2 ? g_force_tile : (env > 0 && env < 4 ? -10 - env : -1);
+}
+static bool wgrad_knob_tmaj()
+{
+  static const bool env_on = !(getenv("DK_WGRAD_TMAJ") && !atoi(getenv("DK_WGRAD_TMAJ")));
+  return g_force_tmaj != -2 ? g_force_tmaj != 0 : env_on;
 }
 
 extern "C" int dk_conv_backward_weights(const DkConvDesc* d, const float* x, const float* delta,
@@ -486,17 +521,16 @@ int dk_conv_backward_weights_cfg(const DkConvDesc* d, const float* x, const floa
     a.size = d->size; a.stride_x = d->stride_x; a.stride_y = d->stride_y;
     a.pad = pad; a.dil = d->dilation;
     int ci = (M > 64 ? 0 : 1) + (K > 64 ? 0 : 2);  // 128/64 rows x 128/64 taps
-    {
-      // DK_WGRAD_TILE=1/2/3: force 64x128 / 128x64 / 64x64 tiles (tuning experiments)
-      static const int force = getenv("DK_WGRAD_TILE") ? atoi(getenv("DK_WGRAD_TILE")) : 0;
-      if (force > 0 && force < 4)
-        ci |= force;
-    }
+    const int knob = wgrad_knob_tile();
+    if (knob <= -11)
+      ci |= -10 - knob;   // DK_WGRAD_TILE=1/2/3: 64x128 / 128x64 / 64x64 tiles (tuning experiments)
     // 3x3 layers with 64 (not 128) channels per tap: 64-tap tiles keep the tap-major path available
     if (d->size > 1 && (C % 128) != 0 && (C % 64) == 0)
       ci |= 2;
     if (cfg_override >= 0 && cfg_override < 4)
       ci = cfg_override;
+    else if (knob >= 0 && knob < 4)
+      ci = knob;
     const WgradCfg& c = g_wcfg[ci];
     const int BM = 64 * c.tm, BKO = 64 * c.tk;
     a.tiles_m = (M + BM - 1) / BM;
@@ -515,9 +549,9 @@ int dk_conv_backward_weights_cfg(const DkConvDesc* d, const float* x, const floa
       a.stages_per_split = 8;
     a.nsplit = (nstages + a.stages_per_split - 1) / a.stages_per_split;
     const long long nblk = tiles * a.nsplit;
-    const bool avec = (a.OHW % 4 == 0) && (((uintptr_t)a.delta & 15) == 0);
+    const bool avec = (a.OHW % 4 == 0) && (((uintptr_t)a.delta & 15) == 0) && g_force_avec != 0;
     // tap-major tiles when a tile never straddles two taps (C a multiple of the tile width) and there is more than one tap
-    static const bool tmaj_on = !(getenv("DK_WGRAD_TMAJ") && !atoi(getenv("DK_WGRAD_TMAJ")));
+    const bool tmaj_on = wgrad_knob_tmaj();
     // (a 1x1 layer is its own tap-major order: same fast gather, no workspace)
     const bool tmaj = tmaj_on && (C % BKO) == 0 && d->pad * d->dilation == (d->size > 1 ? d->pad * d->dilation : 0);
     const int kv = (avec ? 1 : 0) + (tmaj ? 2 : 0);

@@ -48,7 +48,6 @@ int dk_conv_num_configs();
 bool dk_conv_config_applicable(const DkConvDesc* d, int cfg);
 // true for the Winograd 3x3 configurations (they need transformed filters registered for the layer)
 bool dk_conv_config_is_wino(int cfg);
-int dk_transpose_weights_flip(const float* w, float* wt, int M, int C, int size, void* stream);
 // DK_FAST_MISH (default on): closed-form mish / mish gradient instead of the libm chains
 bool dk_fast_mish_enabled();
 // conv3x3_direct_f16.hip: fp16-operand patch-in-LDS kernel with weights pre-packed per layer

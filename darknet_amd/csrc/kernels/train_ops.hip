@@ -21,6 +21,10 @@
 // finalize kernel); the summation order differs from the CPU's sequential fp32
 // loop -- see tests/util.py TRAIN_ATOL_RMS.
 #include <hip/hip_runtime.h>
+
+#include <map>
+#include <mutex>
+#include <utility>
 #include <vector>
 #include <stdint.h>
 #include <stdio.h>
@@ -46,23 +50,27 @@ constexpr int RT = 512;  // threads per reduction workgroup
 // per-device fp64 scratch for the two-stage channel reductions (4 doubles per channel).
 // Zero on entry by contract: it is cleared once when allocated and every finalize kernel clears
 // the entries it has consumed, so no per-call memset is needed (there used to be ~300 per step).
+// (Keyed by device AND stream: replicas that share a device run on streams of their own -- dk_set_thread_stream --
+// and must not share reduction scratch.)
 double* chan_scratch(int filters, hipStream_t st)
 {
-  static double* buf[16];
-  static int cap[16];
-  const int dev = cuda_get_device();
-  if (cap[dev] < filters)
+  struct Buf { double* p = nullptr; int cap = 0; };
+  static std::map<std::pair<int, void*>, Buf> bufs;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  Buf& b = bufs[{cuda_get_device(), (void*)st}];
+  if (b.cap < filters)
   {
-    if (buf[dev])
+    if (b.p)
     {
       CHECK_HIP(hipStreamSynchronize(st));
-      CHECK_HIP(hipFree(buf[dev]));
+      CHECK_HIP(hipFree(b.p));
     }
-    cap[dev] = filters < 4096 ? 4096 : filters;
-    CHECK_HIP(hipMalloc((void**)&buf[dev], (size_t)cap[dev] * 4 * sizeof(double)));
-    CHECK_HIP(hipMemsetAsync(buf[dev], 0, (size_t)cap[dev] * 4 * sizeof(double), st));
+    b.cap = filters < 4096 ? 4096 : filters;
+    CHECK_HIP(hipMalloc((void**)&b.p, (size_t)b.cap * 4 * sizeof(double)));
+    CHECK_HIP(hipMemsetAsync(b.p, 0, (size_t)b.cap * 4 * sizeof(double), st));
   }
-  return buf[dev];
+  return b.p;
 }
 
 // Scratch of the FUSED statistics paths (dk_bn_forward_train, dk_bn_act_backward): the consumer kernel
@@ -71,25 +79,27 @@ double* chan_scratch(int filters, hipStream_t st)
 // steps instead of two tiny finalize launches per layer and pass: 217 launches per yolov4 step).
 double* chan_ring_take(size_t doubles, hipStream_t st)
 {
-  static double* buf[16];
-  static size_t off[16];
+  struct Ring { double* p = nullptr; size_t off = 0; };
+  static std::map<std::pair<int, void*>, Ring> rings;   // per (device, stream), see chan_scratch
+  static std::mutex mu;
   constexpr size_t CAP = (size_t)1 << 20;   // 8 MB
-  const int dev = cuda_get_device();
   if (doubles > CAP)
     return nullptr;
-  if (!buf[dev])
+  std::lock_guard<std::mutex> lk(mu);
+  Ring& r = rings[{cuda_get_device(), (void*)st}];
+  if (!r.p)
   {
-    CHECK_HIP(hipMalloc((void**)&buf[dev], CAP * sizeof(double)));
-    CHECK_HIP(hipMemsetAsync(buf[dev], 0, CAP * sizeof(double), st));
-    off[dev] = 0;
+    CHECK_HIP(hipMalloc((void**)&r.p, CAP * sizeof(double)));
+    CHECK_HIP(hipMemsetAsync(r.p, 0, CAP * sizeof(double), st));
+    r.off = 0;
   }
-  if (off[dev] + doubles > CAP)
+  if (r.off + doubles > CAP)
   {
-    CHECK_HIP(hipMemsetAsync(buf[dev], 0, CAP * sizeof(double), st));
-    off[dev] = 0;
+    CHECK_HIP(hipMemsetAsync(r.p, 0, CAP * sizeof(double), st));
+    r.off = 0;
   }
-  double* p = buf[dev] + off[dev];
-  off[dev] += doubles;
+  double* p = r.p + r.off;
+  r.off += doubles;
   return p;
 }
 
@@ -1245,7 +1255,7 @@ extern "C" int dk_transpose_weights_tapmajor(const float* w, float* wt, int M, i
 
 // wt[c][(m, t)] = w[m][c][ss-1-t]: the weights of the convolution that computes the data
 // gradient of a stride-1 "same" convolution (taps rotated by 180 degrees)
-int dk_transpose_weights_flip(const float* w, float* wt, int M, int C, int size, void* stream)
+extern "C" int dk_transpose_weights_flip(const float* w, float* wt, int M, int C, int size, void* stream)
 {
   const size_t total = (size_t)M * C * size * size;
   if (total == 0)

@@ -53,6 +53,8 @@ DK_API void show_cuda_cudnn_info(void);
 /* streams, src/dark_cuda.c:128-177: one compute + one memcpy stream per device */
 DK_API cudaStream_t get_cuda_stream(void);
 DK_API cudaStream_t get_cuda_memcpy_stream(void);
+/* additive: get_cuda_stream() of the CALLING THREAD returns s until reset with NULL (replicas sharing a device) */
+DK_API void dk_set_thread_stream(cudaStream_t s);
 
 /* allocation + copies, src/dark_cuda.c:259-272, 410-477, 520-559 */
 DK_API float* cuda_make_array(float* x, size_t n);               /* hipMalloc (+ async H2D when x) */

@@ -218,12 +218,24 @@ DK_API int dk_bn_act_backward(float* delta, const float* x, const float* mean, c
  * BackwardConvolutionalLayerGpu, src/convolutional_kernels.cu:757-781). */
 DK_API int dk_conv_backward_weights(const DkConvDesc* d, const float* x, const float* delta,
     float* weight_updates, void* stream);
+/* Test / diagnostics hook: force a variant of the weight-gradient kernel in this process.  knob 0: tile shape 0..3
+ * (128x128, 64x128, 128x64, 64x64 rows x taps), knob 1: tap-major tiles (0 never, 1 where applicable), knob 2: 16-byte
+ * delta loads (0 never); value < 0 restores the default.  Returns the previous value (-1 = default), -3 for an unknown
+ * knob.  Together with dk_conv_force_config (forward / data-gradient kernels) and dk_set_deterministic this reaches every
+ * kernel the training step's first-step timing can choose. */
+DK_API int dk_train_force(int knob, int value);
 /* Data gradient: prev_delta = col2im(W^T * delta), overwriting (dgrad half, :784-812).
  * wt = dk_transpose_weights(weights). */
 DK_API int dk_conv_backward_data(const DkConvDesc* d, const float* delta, const float* wt,
     float* prev_delta, void* stream);
 /* wt[g][c][(m,kh,kw)] = w[g][m][c][kh][kw]; call per group with M = n/groups, C = c/groups */
 DK_API int dk_transpose_weights(const float* w, float* wt, int M, int C, int size, void* stream);
+/* wt[c][m][t] = w[m][c][size*size-1-t]: the filters of the convolution that IS the data gradient of a stride-1 "same"
+ * convolution (taps rotated by 180 degrees); dk_conv_forward on delta with these filters (c <-> n swapped in the
+ * descriptor, no bias, linear) then overwrites prev_delta */
+DK_API int dk_transpose_weights_flip(const float* w, float* wt, int M, int C, int size, void* stream);
+/* 1 when tile / kernel configuration cfg (dk_conv_config_name) can run the layer d */
+DK_API int dk_conv_config_can_run(const DkConvDesc* d, int cfg);
 /* 1: weight gradients and BN channel sums through ordered workspaces instead of atomics (two runs of a training step
  * with the same kernel choices are then bitwise equal); 0: atomics (default, faster); -1: follow DK_DETERMINISTIC */
 DK_API void dk_set_deterministic(int on);

@@ -11,6 +11,7 @@ import netutil
 import synth
 import util
 from oracle import orc_net as O
+from test_gpu_ops import orc_conv
 from test_oracle_golden import inject_yolo_deltas, train_fixture
 
 pytestmark = pytest.mark.gpu
@@ -87,12 +88,156 @@ def test_conv_backward_vs_oracle(gpu, case):
 
 PARITY_CASES = [
     # batch, c, h, w, n, size (stride 2, pad size // 2): the parity-class data gradient of the downsampling layers
+    (8, 32, 608, 608, 64, 3),    # yolov4 layer 1 at the C4 per-GPU batch
     (2, 8, 14, 14, 32, 3),
     (3, 16, 38, 38, 64, 3),      # several pixel tiles per class, class tails are padding
     (1, 32, 76, 52, 96, 3),      # non-square, filters = 3 K tiles of 32
     (2, 32, 304, 304, 64, 3),    # yolov4 layer 1's shape class at half size
     (2, 24, 20, 20, 32, 2),      # 2x2 / stride 2 (one tap per class)
 ]
+
+
+TRAIN_VARIANT_SHAPES = [
+    # batch, c, h, w, n, size (stride 1, pad size // 2): yolov4's C4 layer shapes at the per-GPU batch 8, plus two small
+    # shapes whose channel counts select the other tile / tap-major applicability classes
+    (8, 512, 19, 19, 1024, 3),
+    (8, 256, 38, 38, 512, 3),
+    (8, 128, 76, 76, 128, 3),
+    (8, 64, 304, 304, 64, 1),
+    (2, 64, 19, 19, 128, 3),      # 64 channels per tap: only the 64-tap tiles are tap-major
+    (2, 256, 38, 38, 128, 1),
+    (3, 24, 13, 17, 40, 3),       # ragged everything: no tap-major tile, no 16-byte delta loads
+]
+
+
+def _ran_kernels(L, nslots=512):
+    out = (C.c_double * (3 * nslots))()
+    L.dk_profile_read(out, nslots)
+    L.dk_conv_kernel_name.restype = C.c_char_p
+    names = {}
+    for i in range(nslots):
+        if out[3 * i]:
+            nm = L.dk_conv_kernel_name(i)
+            names[nm.decode() if nm else "slot%d" % i] = int(out[3 * i])
+    return names
+
+
+@pytest.mark.parametrize("case", TRAIN_VARIANT_SHAPES)
+def test_every_training_kernel_variant_vs_oracle(gpu, case):
+    """The training step picks its kernels per layer by first-step timing, so a variant that loses on the test box can
+    win elsewhere: EVERY candidate is forced here (dk_train_force, dk_conv_force_config, dk_set_deterministic) against
+    the oracle's BackwardConvolutionalLayer (src/convolutional_layer.cpp:1307-1380):
+      * weight gradient: 4 tile shapes x tap-major on / off x 16-byte delta loads on / off x atomics / ordered
+        (deterministic) reduction, accumulating into a non-zero dW as the reference does;
+      * data gradient of the stride-1 layers as a forward convolution of delta with the transposed (1x1) or transposed
+        and 180-degree-rotated (3x3) filters, through every forward configuration that can run the layer -- gather
+        tiles, patch-in-LDS, LDS-DMA 1x1, Winograd schedules -- and the gather kernel in data-gradient mode;
+    each launch is checked to have run the kernel it names (profile slots)."""
+    batch, c, h, w, n, size = case
+    pad = size // 2
+    L, G = O.lib(), bind(gpu.lib())
+    G.dk_train_force.argtypes = [C.c_int, C.c_int]
+    G.dk_set_deterministic.argtypes = [C.c_int]
+    G.dk_set_deterministic.restype = None
+    G.dk_transpose_weights_flip.argtypes = [VP, VP, C.c_int, C.c_int, C.c_int, VP]
+    G.dk_conv_config_can_run.argtypes = [VP, C.c_int]
+    rng = np.random.default_rng(abs(hash(case)) & 0xFFFF)
+    x = rng.uniform(-1, 1, (batch, c, h, w)).astype(np.float32)
+    wt = (rng.uniform(-1, 1, (n, c, size, size)) * 0.2).astype(np.float32)
+    delta = rng.uniform(-1, 1, (batch, n, h, w)).astype(np.float32)
+    dw0 = rng.uniform(-1, 1, wt.shape).astype(np.float32)
+    ref_dw, ref_prev = dw0.copy(), np.full_like(x, 3.0)
+    ws = np.zeros(h * w * size * size * c + 1, np.float32)
+    L.orc_conv_backward(O.fptr(x), O.fptr(wt), O.fptr(delta), O.fptr(ref_dw), O.fptr(ref_prev), O.fptr(ws),
+                        batch, c, h, w, n, 1, size, 1, 1, 1, pad)
+    d = gpu.DkConvDesc(batch, c, h, w, n, 1, size, 1, 1, 1, pad, O.LINEAR)
+    dx, dwt, dd = gpu.DeviceArray(x), gpu.DeviceArray(wt), gpu.DeviceArray(delta)
+    K = c * size * size
+    # ---- weight gradient ------------------------------------------------------------------------------------------
+    seen = set()
+    G.dk_profile_enable(1)
+    try:
+        for tile in range(4):
+            tk = 128 if tile in (0, 2) else 64
+            for tmaj in (0, 1):
+                for avec in (0, -1):
+                    for det in (0, 1):
+                        G.dk_train_force(0, tile)
+                        G.dk_train_force(1, tmaj)
+                        G.dk_train_force(2, avec)
+                        G.dk_set_deterministic(det)
+                        ddw = gpu.DeviceArray(dw0)
+                        assert G.dk_conv_backward_weights(C.byref(d), dx.ptr, dd.ptr, ddw.ptr, None) == 0
+                        ran = [k for k in _ran_kernels(gpu.lib()) if k.startswith("conv_wgrad")]
+                        assert len(ran) == 1, ran
+                        want_tmaj = bool(tmaj) and c % tk == 0
+                        want_avec = avec != 0 and (h * w) % 4 == 0
+                        want = "conv_wgrad_f32<%d, %d, %s, %s>" % (2 if tile in (0, 2) else 1, 2 if tile in (0, 1) else 1,
+                                                                  "true" if want_avec else "false", "true" if want_tmaj else "false")
+                        assert ran[0] == want, "forced %s, ran %s" % (want, ran[0])
+                        seen.add((ran[0], det))
+                        util.assert_close(ddw.numpy().reshape(wt.shape), ref_dw,
+                                          "wgrad %s tile %d tap-major %d avec %d deterministic %d" % (case, tile, tmaj, avec, det))
+                        ddw.free()
+    finally:
+        for k in range(3):
+            G.dk_train_force(k, -1)
+        G.dk_set_deterministic(-1)
+        G.dk_profile_enable(0)
+    assert len(seen) >= 8
+    # ---- data gradient as a forward convolution on transposed / rotated filters --------------------------------
+    dt = gpu.DeviceArray(n=wt.size)
+    if size == 3:
+        assert G.dk_transpose_weights_flip(dwt.ptr, dt.ptr, n, c, 3, None) == 0
+    else:
+        assert G.dk_transpose_weights(dwt.ptr, dt.ptr, n, c, 1, None) == 0
+    ddesc = gpu.DkConvDesc(batch, n, h, w, c, 1, size, 1, 1, 1, pad, O.LINEAR)   # channels <-> filters
+    GL = gpu.lib()
+    ncfg = GL.dk_conv_force_config(-1)
+    names = [GL.dk_conv_config_name(i).decode() for i in range(ncfg)]
+    du = None
+    nu = GL.dk_conv_wino_weights_size(C.byref(ddesc))
+    if nu:
+        du = gpu.DeviceArray(n=nu)
+        assert GL.dk_conv_wino_transform_weights(C.byref(ddesc), dt.ptr, du.ptr, None) == 0
+        GL.dk_conv_wino_register(dt.ptr, du.ptr)
+    families = set()
+    try:
+        for cfg in range(ncfg):
+            if not G.dk_conv_config_can_run(C.byref(ddesc), cfg):
+                continue
+            GL.dk_conv_force_config(cfg)
+            G.dk_profile_enable(1)
+            dprev = gpu.DeviceArray(np.full_like(x, 3.0))
+            assert GL.dk_conv_forward(C.byref(ddesc), dd.ptr, dt.ptr, None, dprev.ptr, None, None, None) == 0
+            ran = _ran_kernels(GL)
+            G.dk_profile_enable(0)
+            assert len(ran) == 1, (names[cfg], ran)
+            fam = names[cfg].rstrip("0123456789x_w").split("_")[0] if not names[cfg][0].isdigit() else "gather"
+            kn = list(ran)[0]
+            assert {"gather": "conv_igemm_f32", "direct3x3": "conv3x3_direct_f32", "dma1x1": "conv1x1_dma_f32",
+                    "wino": "conv3x3_wino_f32"}[fam] in kn, "config %s ran %s" % (names[cfg], kn)
+            families.add(fam)
+            util.assert_close(dprev.numpy().reshape(x.shape), ref_prev, "dgrad as convolution %s through %s" % (case, names[cfg]))
+            dprev.free()
+        # and the gather kernel in data-gradient mode (the form the stride-2 layers use), every gather tile
+        dt2 = gpu.DeviceArray(n=wt.size)
+        assert G.dk_transpose_weights(dwt.ptr, dt2.ptr, n, c, size, None) == 0
+        for cfg in range(ncfg):
+            if not names[cfg][0].isdigit():
+                break
+            GL.dk_conv_force_config(cfg)
+            dprev = gpu.DeviceArray(np.full_like(x, 3.0))
+            assert G.dk_conv_backward_data(C.byref(d), dd.ptr, dt2.ptr, dprev.ptr, None) == 0
+            util.assert_close(dprev.numpy().reshape(x.shape), ref_prev, "dgrad (gather mode 1) %s through %s" % (case, names[cfg]))
+            dprev.free()
+    finally:
+        GL.dk_conv_force_config(-1)
+        G.dk_profile_enable(0)
+        if du is not None:
+            GL.dk_conv_wino_register(dt.ptr, None)
+    print("data gradient of %s ran through: %s" % (case, sorted(families)))
+    assert "gather" in families and (size == 1 or "wino" in families or n % 4 or c % 64)
 
 
 @pytest.mark.parametrize("case", PARITY_CASES)
@@ -807,13 +952,85 @@ def test_c4_yolov4_608_b8_train_step_vs_reference_golden(gpu, tmp_path):
     L.DkSetMaxIter(net.p, 1000)
     x = np.ascontiguousarray(synth.make_input(B, net.c, net.h, net.w, seed=12345))
     truth = np.ascontiguousarray(g["truth"])
-    cost = L.TrainNetworkDatum(net.p, x.ctypes.data, truth.ctypes.data)
-    assert abs(cost - float(g["cost"])) <= 2e-3 * float(g["cost"]), (cost, float(g["cost"]))
 
     def pull(i, which, n):
         out = np.empty(n, np.float32)
         assert L.DkLayerPull(net.p, i, which, out.ctypes.data, n) == n
         return out
+    # The step is run through the split API (DkTrainForward / DkBackwardRange / DkTrainFinish == TrainNetworkDatum,
+    # test_split_train_step_equals_train_network_datum) so that the BACKWARD arithmetic of sampled layers can be
+    # checked tightly at this size: before layer l's backward its incoming delta is pulled, after it the delta it left
+    # (conv-output gradient), its weight / scale / bias gradients and the data gradient it wrote into layer l - 1 --
+    # and the oracle's BackwardConvolutionalLayer (activation gradient, batchnorm backward, weight gradient, col2im
+    # data gradient; oracle/orc_net.py backward) is evaluated on exactly those tensors of the HIP path (its input
+    # activations, batch statistics and incoming delta), so kinks take the same branch and the reference's drifted
+    # statistics play no part.  Layers: one of every kernel class the first-step timing chooses among at this size.
+    for fn, at, rt in (("DkTrainForward", [VP, VP, VP], None), ("DkBackwardRange", [VP, C.c_int, C.c_int], None),
+                       ("DkTrainFinish", [VP], C.c_float)):
+        getattr(L, fn).argtypes = at
+        getattr(L, fn).restype = rt
+    SAMPLED = [1, 2, 6, 29, 59, 86, 106, 138]   # 3x3/s2 at 608, 1x1 at 304, 3x3 at 304 / 76, 1x1 at 38, 3x3/s2 -> 19, 3x3 at 19, head
+    OL = O.lib()
+    L.DkTrainForward(net.p, x.ctypes.data, truth.ctypes.data)
+    hi = net.n
+    checked = []
+    for li in sorted(SAMPLED, reverse=True):
+        f, fp = net.info(li), net.info(li - 1)
+        assert f["type"] == O.CONVOLUTIONAL
+        if hi > li + 1:
+            L.DkBackwardRange(net.p, hi, li + 1)
+        n_out = f["batch"] * f["outputs"]
+        delta_in = pull(li, 6, n_out)
+        L.DkBackwardRange(net.p, li + 1, li)
+        hi = li
+        delta_post, dw = pull(li, 6, n_out), pull(li, 7, f["nweights"])
+        prev_delta = pull(li - 1, 6, fp["batch"] * fp["outputs"])
+        x_in = np.ascontiguousarray(net.output(li - 1).reshape(B, f["c"], f["h"], f["w"]))
+        w = pull(li, 1, f["nweights"])
+        n, sp, act = f["n"], f["out_h"] * f["out_w"], f["activation"]
+        raw, _ = orc_conv(x_in, w.reshape(n, f["c"], f["size"], f["size"]), np.zeros(n, np.float32), B, f["c"], f["h"], f["w"], n, f["size"],
+                          f["stride_x"], f["pad"], O.LINEAR)
+        raw = np.ascontiguousarray(raw.reshape(B, n, sp))
+        d = delta_in.copy()
+        out_hip = np.ascontiguousarray(net.output(li).ravel())
+        if f["batch_normalize"]:
+            mean, var, scales, biases = pull(li, 10, n), pull(li, 11, n), pull(li, 3, n), pull(li, 2, n)
+            x_norm = ((raw - mean[None, :, None]) / np.sqrt(var[None, :, None] + np.float32(.000001))).astype(np.float32)
+            pre = np.ascontiguousarray((x_norm * scales[None, :, None] + biases[None, :, None]).astype(np.float32))
+            if act == O.MISH:
+                OL.orc_gradient_array_mish(n_out, O.fptr(pre.ravel()), O.fptr(d))
+            else:
+                OL.orc_gradient_array(O.fptr(out_hip), n_out, act, O.fptr(d))
+            md, vd, su = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+            xn = np.ascontiguousarray(x_norm.ravel())
+            OL.orc_batchnorm_backward(O.fptr(d), B, n, sp, O.fptr(scales), O.fptr(raw.ravel()), O.fptr(xn), O.fptr(mean),
+                                      O.fptr(var), O.fptr(md), O.fptr(vd), O.fptr(su))
+            util.assert_close(pull(li, 9, n), su, "C4 layer %d scale_updates vs oracle on HIP tensors" % li, rel=2e-4,
+                              atol_rms=2 * util.TRAIN_ATOL_RMS)
+        else:
+            OL.orc_gradient_array(O.fptr(out_hip), n_out, act, O.fptr(d))
+            bu = np.zeros(n, np.float32)
+            OL.orc_backward_bias(O.fptr(bu), O.fptr(d), B, n, sp)
+            util.assert_close(pull(li, 8, n), bu, "C4 layer %d bias_updates vs oracle on HIP tensors" % li, rel=2e-4,
+                              atol_rms=2 * util.TRAIN_ATOL_RMS)
+        util.assert_close(delta_post, d, "C4 layer %d delta after activation / batchnorm backward" % li, rel=2e-4,
+                          atol_rms=2 * util.TRAIN_ATOL_RMS)
+        # the weight gradient and the data gradient from the HIP path's own post-batchnorm delta
+        ref_dw, ref_prev = np.zeros(f["nweights"], np.float32), np.zeros(x_in.size, np.float32)
+        ws = np.zeros(sp * f["size"] * f["size"] * f["c"] + 1, np.float32)
+        OL.orc_conv_backward(O.fptr(x_in.ravel()), O.fptr(w), O.fptr(delta_post), O.fptr(ref_dw), O.fptr(ref_prev), O.fptr(ws),
+                             B, f["c"], f["h"], f["w"], n, 1, f["size"], f["stride_x"], f["stride_y"], 1, f["pad"])
+        st_w = util.assert_close(dw, ref_dw, "C4 layer %d weight_updates vs oracle on HIP tensors" % li, rel=2e-4,
+                                 atol_rms=2 * util.TRAIN_ATOL_RMS)
+        st_d = util.assert_close(prev_delta, ref_prev, "C4 layer %d data gradient vs oracle on HIP tensors" % li, rel=2e-4,
+                                 atol_rms=2 * util.TRAIN_ATOL_RMS)
+        checked.append((li, st_w["max_abs_over_rms"], st_d["max_abs_over_rms"]))
+    if hi > 0:
+        L.DkBackwardRange(net.p, hi, 0)
+    cost = L.DkTrainFinish(net.p)
+    print("C4 backward of sampled layers vs the oracle on the HIP path's own tensors (layer, wgrad max|d|/rms, dgrad max|d|/rms): %s"
+          % [(i, float("%.3g" % a), float("%.3g" % b)) for i, a, b in checked])
+    assert abs(cost - float(g["cost"])) <= 2e-3 * float(g["cost"]), (cost, float(g["cost"]))
     # Two comparators per layer (64 strided samples each):
     #  (a) the oracle with the batch statistics accumulated in DOUBLE (orc_set_bn_stats_f64; an analysis
     #      variant, the HIP kernels also reduce in fp64): train-mode tolerance of util.py;
@@ -880,7 +1097,9 @@ def test_c4_yolov4_608_b8_train_step_vs_reference_golden(gpu, tmp_path):
     worst_norm = devs[0][0]
     print("C4 gradient norms vs the reference, largest deviations (dev, layer, 7=weights/9=biases): %s; median %.3g" % (
         [(round(float(d), 4), i, w) for d, i, w in devs[:6]], float(np.median([d for d, _, _ in devs]))))
-    assert float(np.median([d for d, _, _ in devs])) < 3e-2 and worst_norm < 0.25, devs[:6]
+    # (the exact backward check at this size is the per-layer one above; the norms against the reference's own,
+    # drifted step are a sanity bound on the whole: the median, and no gradient tensor off by a factor)
+    assert float(np.median([d for d, _, _ in devs])) < 3e-2 and worst_norm < 0.5, devs[:6]
     print("C4 gradients vs the reference: worst L2-norm deviation %.3g" % worst_norm)
     net.close()
 
