@@ -26,9 +26,16 @@ The JSON line also carries
                    fewer).  `traffic` = HBM bytes per launch of that kernel from the
                    committed rocprofv3 --pmc summary of this workload
                    (profiles/round*_c{2,3,5}/traffic_summary.json).
+                   `frac_executed_mfma` = executed / peak; `algorithmic_bytes` (input + raw filters +
+                   output of the layers that run the kernel, per launch) and `traffic_ratio`; a committed
+                   summary is quoted only when its run.json carries the hash of the library loaded now
+                   (`lib_sha16`), else `traffic` is null and `traffic_source` says why.
   cpu_baseline  -- the reference's CPU path (oracle/_ref/libref_fast.so when it
                    travelled with the repo, else this repo's oracle port) timed
                    on this box's host cores on yolov4 608x608 b=1.
+  other_configs -- (N = 1) the other BASELINE GPU configs in a few seconds each, as child processes:
+                   C2 yolov4-tiny 416 b=32, C5 yolov4-csp and yolov4x-mish 512 b=32 fp16 operands,
+                   C4 yolov4 608 b=8 train step (tools/bench_train.py): value, ms_per_step, dominant kernel, frac.
 """
 import argparse
 import ctypes as C
@@ -49,24 +56,41 @@ CFG = "yolov4"
 BATCH_PER_GPU = 16
 
 
-def pmc_traffic_for(kernel, tag=None):
-    """HBM bytes per launch of `kernel` from the newest committed PMC summary of THIS workload
+def lib_sha16():
+    """First 16 hex digits of the sha256 of the loaded HIP library: ties a committed profile to the build it measured."""
+    import hashlib
+    import darknet_amd as dk
+    h = hashlib.sha256()
+    with open(dk.LIB_PATH, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic_for(kernel, tag):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary of THIS workload AND THIS BUILD
     (profiles/round*_<tag>/traffic_summary.json, produced by tools/make_profiles.sh with this command line:
-    FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc passes); older rounds' summaries are the fallback.
-    None when no summary names the kernel (e.g. the tuner picked a kernel the profiled run did not use)."""
+    FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc passes).  A summary is used only when the `lib_sha16` its
+    run.json recorded equals the hash of the library loaded now -- a profile of an older build of a kernel with the
+    same name would otherwise be quoted silently.  Returns (bytes or None, why)."""
     import glob
-    files = []
-    if tag:
-        files += sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_%s" % tag, "traffic_summary.json")), reverse=True)
-    files += sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True)
-    for f in files:
+    if not tag:
+        return None, "no committed profile for this workload"
+    mine = lib_sha16()
+    why = "no committed profile names this kernel"
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_%s" % tag, "traffic_summary.json")), reverse=True):
         try:
+            run = json.load(open(os.path.join(os.path.dirname(f), "run.json")))
+            if run.get("lib_sha16") != mine:
+                why = "the committed profile (%s) measured another build (lib_sha16 %s, loaded %s)" % (
+                    os.path.relpath(os.path.dirname(f), ROOT), run.get("lib_sha16"), mine)
+                continue
             for r in json.load(open(f)):
                 if kernel in r["kernel"]:
-                    return r["hbm_bytes_per_launch"]
+                    return r["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
         except Exception:
             pass
-    return None
+    return None, why
 
 
 def log(*a):
@@ -83,6 +107,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--half", action="store_true", help="fp16 operands / fp32 accumulate on the layers the reference's rule admits (config C5)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short C2 / C4 / C5 legs of the N = 1 line")
     args = ap.parse_args()
 
     # N > 1 without a launcher: start the N ranks ourselves as fresh child processes (one per GPU,
@@ -137,6 +162,8 @@ def main():
     L.dk_conv_kernel_name.argtypes = [C.c_int]
     L.cuda_push_array(L.DkNetworkInputGpu(net.p), x.ctypes.data, x.size)
     L.NetworkSync(net.p)
+
+    net_w, net_h = net.w, net.h
 
     def step():
         L.NetworkPredictDevice(net.p, None)
@@ -222,18 +249,37 @@ def main():
         kname = L.dk_conv_kernel_name(ci).decode()
         # profiles/round<N>_{c3,c2,c5}: the BASELINE configs the summaries were taken on
         tag = {"yolov4": "c3", "yolov4-tiny": "c2", "yolov4-csp": "c5"}.get(args.cfg)
-        traffic = pmc_traffic_for(kname, tag)
+        traffic, traffic_src = pmc_traffic_for(kname, tag)
         # the dominant kernel's own arithmetic decides its roof: fp16-operand kernels run on the fp16 MFMA pipe
         peak = FP16_MFMA_PEAK_TFLOPS if "f16" in kname else FP32_MFMA_PEAK_TFLOPS
+        # ALGORITHMIC bytes per launch of that kernel (every tensor once): input + raw filters + output
+        # (+ the residual a fused shortcut reads) of the layers that run it, launch-weighted
+        L.DkLayerConvCfg.argtypes = [C.c_void_p, C.c_int]
+        L.DkLayerFused.argtypes = [C.c_void_p, C.c_int]
+        alg, nl = 0.0, 0
+        for i in range(net.n):
+            f = net.info(i)
+            if f["type"] != 0 or L.DkLayerConvCfg(net.p, i) != ci // 4:
+                continue
+            if "wino" in kname and ((f["out_w"] % 2 == 0) != ("true" in kname.split(",")[1])):
+                continue   # the paired-store and the single-store instantiation are different kernels
+            out_b = 4.0 * args.batch * f["outputs"]
+            alg += 4.0 * args.batch * f["inputs"] + 4.0 * f["nweights"] + out_b * (2 if L.DkLayerFused(net.p, i) else 1)
+            nl += 1
+        alg_per_launch = alg / nl if nl else None
+        executed = achieved / 2.25 if "wino" in kname else achieved
         roofline = {
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-            "frac": achieved / peak, "traffic": traffic,
+            "frac": achieved / peak,
+            # Winograd launches are booked with the DIRECT algorithm's FLOPs (SURVEY 8d's per-layer figure), so `frac` can
+            # exceed what the pipe does: `frac_executed_mfma` is the share of the MFMA peak the pipe really executes
+            "mfma_executed_tflops": executed, "frac_executed_mfma": executed / peak,
+            "traffic": traffic, "traffic_source": traffic_src,
             "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate "
                             "rocprofv3 --pmc passes of this command: tools/make_profiles.sh -> profiles/round*/)",
+            "algorithmic_bytes": alg_per_launch,
+            "traffic_ratio": (traffic / alg_per_launch) if (traffic and alg_per_launch) else None,
             "kernel": kname,
-            # Winograd launches are booked with the DIRECT algorithm's FLOPs (SURVEY 8d's per-layer figure):
-            # `achieved` is algorithmic; the MFMA pipe executes 2.25x fewer
-            "mfma_executed_tflops": achieved / 2.25 if "wino" in kname else achieved,
             "launches_per_step": launches / prof_steps,
             "gflop_per_launch": gflop / launches, "avg_launch_ms": ms / launches,
             "all_conv_kernels": {"achieved": tot_gf / tot_ms, "frac": tot_gf / tot_ms / FP32_MFMA_PEAK_TFLOPS,
@@ -263,6 +309,33 @@ def main():
         except Exception as e:  # the baseline is reported, never required
             log("cpu_baseline failed:", e)
 
+    # ---- the other BASELINE GPU configs, a few seconds each (N = 1 line of the headline workload only): child
+    # processes of this script / tools/bench_train.py after this process has released the GPU work above
+    other = None
+    if (ctx.rank == 0 and ctx.world == 1 and args.cfg == CFG and args.batch == BATCH_PER_GPU and not args.half
+            and not args.no_other_configs):
+        def leg(cmd):
+            try:
+                r = subprocess.run([sys.executable] + cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=280)
+                d = json.loads(r.stdout.decode().strip().splitlines()[-1])
+                rf = d.get("roofline") or {}
+                return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d.get("steps"),
+                        "workload": d["config"]["workload"], "dominant_kernel": rf.get("kernel"), "frac": rf.get("frac"),
+                        "frac_executed_mfma": rf.get("frac_executed_mfma"),
+                        "frac_of_fp32_mfma_roofline": d.get("frac_of_fp32_mfma_roofline")}
+            except Exception as e:
+                return {"error": str(e)[:200]}
+        me = os.path.abspath(__file__)
+        common = ["--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--no-other-configs"]
+        net.close()   # (12 GB of activations: the legs get the whole card)
+        net = None
+        other = {
+            "c2_yolov4_tiny_416_b32_fwd": leg([me, "--cfg", "yolov4-tiny", "--batch", "32"] + common),
+            "c5_yolov4_csp_512_b32_half_fwd": leg([me, "--cfg", "yolov4-csp", "--batch", "32", "--half"] + common),
+            "c5_yolov4x_mish_512_b32_half_fwd": leg([me, "--cfg", "yolov4x-mish", "--batch", "32", "--half"] + common),
+            "c4_yolov4_608_b8_train_step": leg([os.path.join(ROOT, "tools", "bench_train.py"), "--steps", "10", "--warmup", "3"]),
+        }
+
     if ctx.rank == 0:
         res = {
             "metric": "images/sec YOLOv4 608x608 fwd" if args.cfg == "yolov4" else "images/sec %s fwd" % args.cfg,
@@ -272,7 +345,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16 operands / f32 accumulate (eligible 3x3 layers), f32 elsewhere" if args.half else "f32", "data": "synthetic",
             "config": {"workload": "%s.cfg %dx%d batch=%d/GPU forward, BN folded, bias+mish/leaky fused%s"
-                                   % (args.cfg, net.w, net.h, args.batch,
+                                   % (args.cfg, net_w, net_h, args.batch,
                                       " (BASELINE configs[2])" if (args.cfg == "yolov4" and args.batch == 16 and not args.half) else ""),
                        "global_batch": args.batch * ctx.world,
                        "parallelism": "batch-sharded replicas x%d, no data-path collective" % ctx.world},
@@ -284,11 +357,14 @@ def main():
             "e2e_u8_note": "u8 HWC frames -> device Mat2Image -> forward -> device candidate compaction -> "
                            "Detection arrays for every image; threshold passes %.0f predictors/image" % (ndet / args.batch),
             "load_seconds_incl_autotune": load_seconds,
+            "lib_sha16": lib_sha16(),
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
+            "other_configs": other,
         }
         print(json.dumps(res), flush=True)
-    net.close()
+    if net is not None:
+        net.close()
     ctx.close()
 
 

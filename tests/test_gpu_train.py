@@ -153,12 +153,17 @@ def test_every_training_kernel_variant_vs_oracle(gpu, case):
     d = gpu.DkConvDesc(batch, c, h, w, n, 1, size, 1, 1, 1, pad, O.LINEAR)
     dx, dwt, dd = gpu.DeviceArray(x), gpu.DeviceArray(wt), gpu.DeviceArray(delta)
     K = c * size * size
+    # a weight gradient is a sum of N = batch * oh * ow products per element; the oracle adds them sequentially in fp32
+    # (gemm_nt, as the reference does), which alone carries ~sqrt(N) * 2^-24 relative noise: 5e-5 x rms at N = 739 k
+    # (the 304x304 layers at b = 8; measured HIP-vs-oracle there: 3.2e-5).  Bound: util's 1e-5 x rms up to N = 10 k,
+    # growing with sqrt(N) beyond.
+    wg_atol = max(util.ATOL_RMS, 1e-7 * float(np.sqrt(batch * h * w)))
     # ---- weight gradient ------------------------------------------------------------------------------------------
     seen = set()
     G.dk_profile_enable(1)
     try:
         for tile in range(4):
-            tk = 128 if tile in (0, 2) else 64
+            tk = 128 if tile in (0, 1) else 64
             for tmaj in (0, 1):
                 for avec in (0, -1):
                     for det in (0, 1):
@@ -177,7 +182,8 @@ def test_every_training_kernel_variant_vs_oracle(gpu, case):
                         assert ran[0] == want, "forced %s, ran %s" % (want, ran[0])
                         seen.add((ran[0], det))
                         util.assert_close(ddw.numpy().reshape(wt.shape), ref_dw,
-                                          "wgrad %s tile %d tap-major %d avec %d deterministic %d" % (case, tile, tmaj, avec, det))
+                                          "wgrad %s tile %d tap-major %d avec %d deterministic %d" % (case, tile, tmaj, avec, det),
+                                          atol_rms=wg_atol)
                         ddw.free()
     finally:
         for k in range(3):
@@ -213,7 +219,7 @@ def test_every_training_kernel_variant_vs_oracle(gpu, case):
             ran = _ran_kernels(GL)
             G.dk_profile_enable(0)
             assert len(ran) == 1, (names[cfg], ran)
-            fam = names[cfg].rstrip("0123456789x_w").split("_")[0] if not names[cfg][0].isdigit() else "gather"
+            fam = names[cfg].split("_")[0] if not names[cfg][0].isdigit() else "gather"
             kn = list(ran)[0]
             assert {"gather": "conv_igemm_f32", "direct3x3": "conv3x3_direct_f32", "dma1x1": "conv1x1_dma_f32",
                     "wino": "conv3x3_wino_f32"}[fam] in kn, "config %s ran %s" % (names[cfg], kn)
@@ -926,6 +932,36 @@ def test_train_networks_c_entry_equals_subdivisions(gpu, tmp_path):
             util.assert_close(b0, a, "weights after %d TrainNetworks steps, layer %d" % (STEPS, i), rel=2e-5, atol_rms=2e-6)
     L.DkNetworkArrayDestroy(nets, B)
     ref.close()
+
+
+def test_train_networks_collective_path_on_one_gpu(gpu, tmp_path):
+    """The RCCL branch of TrainNetworks / SyncNetworks (csrc/host/multigpu.cpp; reference network_kernels.cu:398-484)
+    EXECUTED on a one-GPU box: a child process (the environment selects the path before the library loads) runs two
+    replicas of yolov4-tiny on device 0 with DK_DP_SHARED_DEVICE_COLLECTIVE=1 -- two concurrent host threads, each on
+    its own compute stream with its own reduction scratch, the gradient bucket all-reduced in backward-order segments on
+    the communication stream behind events, threaded update, SyncNetworks' per-tensor all-reduces -- with
+    tests/libshim_rccl.so (host-staged sums; built from tests/shim_rccl.cpp) standing in for librccl through
+    DK_RCCL_LIB.  In deterministic mode the replicas must stay bitwise identical and match ONE replica accumulating
+    over subdivisions = 2 (same tolerance as the local-sum test: the two sums associate differently); the shim must
+    have seen >= 2 segments per iteration, from both ranks at once.  What this does NOT show: anything about RCCL
+    itself or xGMI -- multi-GPU runs are the driver's."""
+    import subprocess
+    import sys
+    shim_src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "shim_rccl.cpp")
+    shim = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libshim_rccl.so")
+    if not os.path.exists(shim) or os.path.getmtime(shim) < os.path.getmtime(shim_src):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "-O2", shim_src, "-o", shim, "-lpthread"])
+    g, cfg, wpath, x = train_fixture(tmp_path)
+    np.save(str(tmp_path / "x.npy"), x)
+    np.save(str(tmp_path / "truth.npy"), g["truth"])
+    env = dict(os.environ, DK_RCCL_LIB=shim, DK_DP_SHARED_DEVICE_COLLECTIVE="1", DK_DETERMINISTIC="1", DK_DP_SEGMENTS="3",
+               PYTHONPATH=os.pathsep.join([os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__)))]))
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dp_child.py")
+    r = subprocess.run([sys.executable, child, cfg, wpath, str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode()
+    print(out[-3000:])
+    assert r.returncode == 0, out[-3000:]
+    assert "DP-CHILD-OK" in out
 
 
 def test_c4_yolov4_608_b8_train_step_vs_reference_golden(gpu, tmp_path):

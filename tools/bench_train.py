@@ -41,6 +41,19 @@ def main():
     ap.add_argument("--cfg", default="yolov4")
     ap.add_argument("--batch", type=int, default=8)
     a = ap.parse_args()
+    # N > 1 without a launcher: start the N ranks as fresh child processes (one per GPU, rendezvous on 127.0.0.1) BEFORE
+    # anything here touches the GPU, relay rank 0's JSON line and exit with the children's code (as bench.py does)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
     import numpy as np
     import torch
     import darknet_amd as dk
@@ -102,7 +115,7 @@ def main():
                                  "tflops": r[2] / r[0]} for r in rows[:10]]}
         gf_img = {"yolov4": 128.459, "yolov4-tiny": 6.910, "yolov4-csp": 77.003}.get(a.cfg)
         print(json.dumps({"metric": "images/sec %s train step" % a.cfg, "value": rate, "unit": "images/sec", "n_gpus": ctx.world,
-                          "ms_per_step": 1000 * tmax / a.steps, "batch_per_gpu": a.batch, "last_cost": cost,
+                          "ms_per_step": 1000 * tmax / a.steps, "steps": a.steps, "batch_per_gpu": a.batch, "last_cost": cost,
                           "frac_of_fp32_mfma_roofline": (rate * 3 * gf_img * 1e9 / (ctx.world * 157.3e12)) if gf_img else None,
                           "config": {"workload": "%s.cfg %dx%d batch=%d/GPU train step (forward with batch statistics, host yolo loss, "
                                                  "backward, gradient all-reduce, SGD)" % (a.cfg, net.w, net.h, a.batch)},

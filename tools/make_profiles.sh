@@ -7,7 +7,7 @@ set -e
 OUT=${1:-gpurun_out/final}
 shift || true
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-if [ $# -eq 0 ]; then set -- bench.py --steps 20 --warmup 3 --no-cpu-baseline; fi
+if [ $# -eq 0 ]; then set -- bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs; fi
 SCRIPT=$R/$1
 shift
 mkdir -p $R/$OUT
