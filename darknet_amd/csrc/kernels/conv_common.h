@@ -277,9 +277,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
   // residual values of the group are fetched first, so the loads overlap instead
   // of being serialised behind the stores; the row part of every address is a
   // scalar offset (soffset), the per-lane part is loop invariant.
-  using std::false_type;
-  using std::true_type;
-  using std::integral_constant;
   auto emit_fast = [&](auto actc, auto resc) {
     constexpr int ACT = decltype(actc)::value;
     constexpr bool RES = decltype(resc)::value;
@@ -289,65 +286,46 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
     unsigned vo[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) vo[j] = obase[j] + (unsigned)(mlane - msub) * row_bytes;
-    // Every bias value of the wave's rows is requested before the first store, and the residual values of row group
-    // g + 1 before the stores of group g: the compiler may not move a load above a store to a buffer that could alias,
-    // so loads issued inside the store loop are serialised behind the previous group's stores and each group pays a
-    // full global-load latency (4 x TM of them per tile; on the short-K 1x1 layers that was most of the epilogue).
-    float bvall[TM][16];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
+    {
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        bvall[i][r] = __uint_as_float(
-            __builtin_amdgcn_raw_buffer_load_b32(br, mlane * 4, (i * 32 + 8 * (r >> 2) + (r & 3)) * 4, 0));
-    float res[2][4][TN];
-    auto load_res = [&](auto gc) {
-      constexpr int g = decltype(gc)::value;
-      constexpr int i = g >> 2, q = g & 3;
-      if constexpr (RES && g < 4 * TM)
+      for (int q = 0; q < 4; ++q)
       {
+        float bv[4], res[4][TN];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          bv[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(br, mlane * 4, (i * 32 + 8 * q + t) * 4, 0));
+        if (RES)
+        {
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              res[t][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                  rr, (int)vo[j], (i * 32 + 8 * q + t) * (int)row_bytes, 0));
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            res[g & 1][t][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                rr, (int)vo[j], (i * 32 + 8 * q + t) * (int)row_bytes, 0));
+          {
+            float v = acc[i][j][4 * q + t] + bv[t];
+            if (ACT == DK_MISH)
+              v = dk_mish_fast(v);
+            else if (ACT == DK_LEAKY)
+              v = dk_leaky(v);
+            if (RES)
+              v += res[t][j];
+            __builtin_amdgcn_raw_buffer_store_b32(
+                __float_as_uint(v), yr, (int)vo[j], (i * 32 + 8 * q + t) * (int)row_bytes, 0);
+          }
       }
-    };
-    auto do_group = [&](auto gc) {
-      constexpr int g = decltype(gc)::value;
-      constexpr int i = g >> 2, q = g & 3;
-      load_res(integral_constant<int, g + 1>{});
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-        {
-          float v = acc[i][j][4 * q + t] + bvall[i][4 * q + t];
-          if (ACT == DK_MISH)
-            v = dk_mish_fast(v);
-          else if (ACT == DK_LEAKY)
-            v = dk_leaky(v);
-          if (RES)
-            v += res[g & 1][t][j];
-          __builtin_amdgcn_raw_buffer_store_b32(
-              __float_as_uint(v), yr, (int)vo[j], (i * 32 + 8 * q + t) * (int)row_bytes, 0);
-        }
-    };
-    load_res(integral_constant<int, 0>{});
-    do_group(integral_constant<int, 0>{});
-    do_group(integral_constant<int, 1>{});
-    do_group(integral_constant<int, 2>{});
-    do_group(integral_constant<int, 3>{});
-    if constexpr (TM > 1)
-    {
-      do_group(integral_constant<int, 4>{});
-      do_group(integral_constant<int, 5>{});
-      do_group(integral_constant<int, 6>{});
-      do_group(integral_constant<int, 7>{});
     }
-    static_assert(TM <= 2, "conv_epilogue: row groups are spelled out for TM <= 2");
   };
+  using std::false_type;
+  using std::true_type;
+  using std::integral_constant;
   if (full_tile && !has_ain)
   {
     if (act == (DK_MISH | DK_ACT_FAST))

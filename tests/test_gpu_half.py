@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 def test_conv_half_vs_rounded_oracle(gpu, case):
     batch, c, h, w, n, size, stride, pad, actname = case
     act = getattr(O, actname)
-    rng = np.random.default_rng(abs(hash(case)) & 0xFFFF)
+    rng = np.random.default_rng(util.seed_of(case))
     x = rng.uniform(-1, 1, (batch, c, h, w)).astype(np.float32)
     wt = (rng.uniform(-1, 1, (n, c, size, size)) * np.sqrt(2.0 / (size * size * c))).astype(np.float32)
     bias = rng.uniform(-.5, .5, n).astype(np.float32)
@@ -45,10 +45,13 @@ def test_conv_half_vs_rounded_oracle(gpu, case):
                                   (1, 128, 64, 64, 128, "MISH"), (1, 16, 128, 128, 40, "LINEAR"), (3, 48, 16, 16, 136, "LEAKY")])
 def test_conv_half_direct_vs_rounded_oracle(gpu, case):
     """The patch-in-LDS fp16 kernel (weights packed [n][c/16][tap][16]) against the CPU fp32 path
-    on fp16-rounded inputs and weights, with and without a residual."""
+    on fp16-rounded inputs and weights, with and without a residual.  The products of fp16 operands are exact in
+    fp32 and both sides accumulate in fp32, but in different orders (the kernel walks 16-channel stages tap-major, the
+    oracle's gemm_nn is k-ascending): at K = 4608 that is 1.5e-5 x rms on single elements (measured), so the
+    element-wise floor is 2e-5 x rms here instead of util's 1e-5."""
     batch, c, h, w, n, actname = case
     act = getattr(O, actname)
-    rng = np.random.default_rng(abs(hash(case)) & 0xFFFF)
+    rng = np.random.default_rng(util.seed_of(case))
     x = rng.uniform(-1, 1, (batch, c, h, w)).astype(np.float32)
     wt = (rng.uniform(-1, 1, (n, c, 3, 3)) * np.sqrt(2.0 / (9 * c))).astype(np.float32)
     bias = rng.uniform(-.5, .5, n).astype(np.float32)
@@ -74,9 +77,9 @@ def test_conv_half_direct_vs_rounded_oracle(gpu, case):
     want = wt.astype(np.float16).reshape(n, c // 16, 16, 9).transpose(0, 1, 3, 2)
     assert np.array_equal(packed, want)
     assert L.dk_conv_forward_half_packed(C.byref(d), dx.ptr, dp.ptr, db.ptr, dy.ptr, dr.ptr, None) == 0
-    util.assert_close(dy.numpy().reshape(ref.shape), ref + res, "fp16 direct conv + residual %s" % (case,))
+    util.assert_close(dy.numpy().reshape(ref.shape), ref + res, "fp16 direct conv + residual %s" % (case,), atol_rms=2e-5)
     assert L.dk_conv_forward_half_packed(C.byref(d), dx.ptr, dp.ptr, db.ptr, dy.ptr, None, None) == 0
-    util.assert_close(dy.numpy().reshape(ref.shape), ref, "fp16 direct conv %s" % (case,))
+    util.assert_close(dy.numpy().reshape(ref.shape), ref, "fp16 direct conv %s" % (case,), atol_rms=2e-5)
 
 
 def test_csp_b1_half_vs_rounded_oracle(gpu, tmp_path):

@@ -53,7 +53,7 @@ CONV_CASES = [
 def test_conv_forward_vs_oracle(gpu, case):
     batch, c, h, w, n, size, stride, pad, actname, groups, dil = case
     act = getattr(O, actname) if hasattr(O, actname) else {"RELU": 1, "RELU6": 2, "SWISH": 16}[actname]
-    rng = np.random.default_rng(hash(case) & 0xFFFF)
+    rng = np.random.default_rng(util.seed_of(case))
     x = rng.uniform(-1, 1, (batch, c, h, w)).astype(np.float32)
     fan = size * size * c // groups
     wt = (rng.uniform(-1, 1, (n, c // groups, size, size)) * np.sqrt(2.0 / fan)).astype(np.float32)
@@ -90,7 +90,7 @@ def test_conv_direct3x3_vs_oracle(gpu, case):
     activation and a residual (the straight-line epilogue), against the CPU oracle."""
     batch, c, h, w, n, actname = case
     act = getattr(O, actname)
-    rng = np.random.default_rng(hash(case) & 0xFFFF)
+    rng = np.random.default_rng(util.seed_of(case))
     x = rng.uniform(-1, 1, (batch, c, h, w)).astype(np.float32)
     wt = (rng.uniform(-1, 1, (n, c, 3, 3)) * np.sqrt(2.0 / (9 * c))).astype(np.float32)
     bias = rng.uniform(-.5, .5, n).astype(np.float32)
@@ -318,7 +318,7 @@ def test_conv_dma1x1_vs_oracle(gpu, case):
     (straight-line epilogue), and BITWISE equal to the gather kernel (same k order, same MFMA chain)."""
     batch, c, h, w, n, actname = case
     act = getattr(O, actname)
-    rng = np.random.default_rng(hash(case) & 0xFFFF)
+    rng = np.random.default_rng(util.seed_of(case))
     x = rng.uniform(-1, 1, (batch, c, h, w)).astype(np.float32)
     wt = (rng.uniform(-1, 1, (n, c, 1, 1)) * np.sqrt(2.0 / c)).astype(np.float32)
     bias = rng.uniform(-.5, .5, n).astype(np.float32)
@@ -374,7 +374,7 @@ def test_conv_winograd_vs_oracle(gpu, case):
     the fp32 tolerance of util.py, and the measured distance is printed next to the direct kernel's."""
     batch, c, h, w, n, actname, with_res = case
     act = getattr(O, actname)
-    rng = np.random.default_rng(hash(case) & 0xFFFF)
+    rng = np.random.default_rng(util.seed_of(case))
     x = rng.uniform(-1, 1, (batch, c, h, w)).astype(np.float32)
     wt = (rng.uniform(-1, 1, (n, c, 3, 3)) * np.sqrt(2.0 / (9 * c))).astype(np.float32)
     bias = rng.uniform(-.5, .5, n).astype(np.float32)
