@@ -730,6 +730,88 @@ float* NetworkPredictGpu(Network* net, float* input)
 
 float* NetworkPredict(Network* net, float* input) { return NetworkPredictGpu(net, input); }
 
+// Staged inputs cross PCIe on a stream of their own: on the shared copy stream they would queue behind the D2H of the
+// previous batch's heads (123 MB for yolov4 b=16) and start only when that forward has finished.
+static hipStream_t stage_stream_of(Network* net)
+{
+  if (!net->stage_stream)
+  {
+    hipStream_t s;
+    CHECK_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    net->stage_stream = s;
+  }
+  return (hipStream_t)net->stage_stream;
+}
+
+static void free_float_stage(Network* net)
+{
+  if (net->f32_stage_gpu) (void)hipFree(net->f32_stage_gpu);
+  if (net->f32_stage_pinned) (void)hipHostFree(net->f32_stage_pinned);
+  net->f32_stage_gpu = net->f32_stage_pinned = nullptr;
+  net->f32_stage_floats = 0;
+  net->f32_copy_pending = net->f32_staged = 0;
+}
+
+void DkNetworkStageFloat(Network* net, const float* input)
+{
+  if (net->gpu_index < 0)
+    error("DkNetworkStageFloat: no HIP device (this library has no CPU fallback)");
+  if (net->gpu_index != cuda_get_device())
+    cuda_set_device(net->gpu_index);
+  const size_t size = (size_t)GetNetworkInputSize(net) * net->batch;
+  if (net->f32_stage_floats != size)
+  {
+    NetworkSync(net);
+    free_float_stage(net);
+    CHECK_HIP(hipMalloc((void**)&net->f32_stage_gpu, size * sizeof(float)));
+    CHECK_HIP(hipHostMalloc((void**)&net->f32_stage_pinned, size * sizeof(float), hipHostMallocDefault));
+    net->f32_stage_floats = size;
+  }
+  if (!net->f32_h2d_ev)
+  {
+    hipEvent_t a, b;
+    CHECK_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+    CHECK_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+    net->f32_h2d_ev = a;
+    net->f32_copy_ev = b;
+  }
+  // the device copy that read the staging buffer (previous DkNetworkPredictStaged) must be done before it is refilled;
+  // it waited for the previous H2D, so the pinned buffer is free as well
+  if (net->f32_copy_pending)
+  {
+    CHECK_HIP(hipEventSynchronize((hipEvent_t)net->f32_copy_ev));
+    net->f32_copy_pending = 0;
+  }
+  else if (net->f32_staged)
+    CHECK_HIP(hipEventSynchronize((hipEvent_t)net->f32_h2d_ev));   // re-staging without a forward in between
+  static const int want = getenv("DK_STAGE_THREADS") ? atoi(getenv("DK_STAGE_THREADS")) : 4;
+  const size_t piece = (size_t)1 << 20;   // floats (4 MB)
+  const int npieces = (int)((size + piece - 1) / piece);
+  int nthreads = want < 1 ? 1 : want;
+  if (nthreads > npieces) nthreads = npieces;
+  hipStream_t ss = stage_stream_of(net);
+  const int dev = cuda_get_device();
+  std::atomic<int> next(0);
+  auto work = [&]() {
+    (void)hipSetDevice(dev);
+    for (;;)
+    {
+      const int k = next.fetch_add(1);
+      if (k >= npieces)
+        return;
+      const size_t off = (size_t)k * piece, n = (off + piece <= size) ? piece : size - off;
+      memcpy(net->f32_stage_pinned + off, input + off, n * sizeof(float));
+      CHECK_HIP(hipMemcpyAsync(net->f32_stage_gpu + off, net->f32_stage_pinned + off, n * sizeof(float), hipMemcpyHostToDevice, ss));
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < nthreads; ++t) pool.emplace_back(work);
+  work();
+  for (std::thread& t : pool) t.join();
+  CHECK_HIP(hipEventRecord((hipEvent_t)net->f32_h2d_ev, ss));
+  net->f32_staged = 1;
+}
+
 // the input step before the path.  The frames cross PCIe as bytes (4x fewer
 // than floats) and Mat2Image's arithmetic runs on the device.
 static void stage_frames(Network* net, const unsigned char* frames_hwc, int src_w, int src_h, size_t row_step, int swap_rb);
@@ -788,7 +870,7 @@ static void stage_frames(Network* net, const unsigned char* frames_hwc, int src_
   unsigned char* pinned = slot ? net->u8_pinned2 : net->u8_pinned;
   unsigned char* dev = slot ? net->u8_gpu2 : net->u8_gpu;
   memcpy(pinned, frames_hwc, bytes);
-  hipStream_t cs = get_cuda_memcpy_stream();
+  hipStream_t cs = stage_stream_of(net);
   CHECK_HIP(hipMemcpyAsync(dev, pinned, bytes, hipMemcpyHostToDevice, cs));
   CHECK_HIP(hipEventRecord((hipEvent_t)net->u8_h2d_ev[slot], cs));
   net->u8_staged = slot + 1;
@@ -803,10 +885,23 @@ void DkNetworkPredictStaged(Network* net)
 {
   if (net->gpu_index < 0)
     error("DkNetworkPredictStaged: no HIP device (this library has no CPU fallback)");
-  if (net->u8_staged < 1)
-    error("DkNetworkPredictStaged: no frames staged (call DkNetworkStageU8 first)");
   if (net->gpu_index != cuda_get_device())
     cuda_set_device(net->gpu_index);
+  if (net->f32_staged)
+  {
+    hipStream_t st = get_cuda_stream();
+    CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)net->f32_h2d_ev, 0));
+    // (stream order puts the copy behind the previous forward's reads of the input tensor)
+    CHECK_HIP(hipMemcpyAsync(net->input_state_gpu, net->f32_stage_gpu, net->f32_stage_floats * sizeof(float),
+        hipMemcpyDeviceToDevice, st));
+    CHECK_HIP(hipEventRecord((hipEvent_t)net->f32_copy_ev, st));
+    net->f32_copy_pending = 1;
+    net->f32_staged = 0;
+    NetworkPredictDevice(net, nullptr);
+    return;
+  }
+  if (net->u8_staged < 1)
+    error("DkNetworkPredictStaged: nothing staged (call DkNetworkStageU8 / DkNetworkStageFrames / DkNetworkStageFloat first)");
   const int slot = net->u8_staged - 1;
   hipStream_t st = get_cuda_stream();
   // stream order already puts the conversion behind the previous forward's reads of the input tensor
@@ -1336,6 +1431,10 @@ void FreeNetwork(Network* net)
     cuda_free((float*)net->cand_counter_gpu);
     if (net->nms_heads_gpu) (void)hipFree(net->nms_heads_gpu);
     if (net->cand_host) cuda_free_host(net->cand_host);
+    free_float_stage(net);
+    if (net->f32_h2d_ev) (void)hipEventDestroy((hipEvent_t)net->f32_h2d_ev);
+    if (net->f32_copy_ev) (void)hipEventDestroy((hipEvent_t)net->f32_copy_ev);
+    if (net->stage_stream) (void)hipStreamDestroy((hipStream_t)net->stage_stream);
     if (net->u8_gpu) (void)hipFree(net->u8_gpu);
     if (net->u8_pinned) (void)hipHostFree(net->u8_pinned);
     if (net->u8_gpu2) (void)hipFree(net->u8_gpu2);

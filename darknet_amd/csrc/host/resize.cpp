@@ -253,6 +253,7 @@ void ResizeNetwork(Network* net, int w, int h)
       if (net->layers[i].type == CONVOLUTIONAL)
         DkConvPrepare(&net->layers[i]);
     net->cand_valid = 0;
+    net->f32_staged = 0;   // a float batch staged for the old resolution is dropped (DkNetworkStageFloat re-allocates)
     CHECK_HIP(hipStreamSynchronize(get_cuda_stream()));
     // the device-NMS head table holds the yolo grid sizes: rebuilt on the next DkGetNetworkBoxesNms
     if (net->nms_heads_gpu)

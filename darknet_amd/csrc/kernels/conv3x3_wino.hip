@@ -418,6 +418,26 @@ __global__ void __launch_bounds__(512) conv3x3_wino_f32(const ConvArgs p)
   const unsigned u_lds = lds0 + (unsigned)(wq * 64) * 16u;                               // + slot * 16 KB + j * 4 KB
   const unsigned r_lds = lds0 + (unsigned)((D + 2) * W_STAGE) * 4u + (unsigned)(wq * 64 * VW) * 4u;   // + slot * RAWF * 4 + k * 256 * VW * 4
 
+  // The filters of the first two stages depend on nothing computed below: their LDS-DMA goes out FIRST, so its latency
+  // runs under the index arithmetic, the piece offsets and the zeroing of the raw ring (round 3: the prologue was 9 400
+  // of a [128->128 76x76] workgroup's 145 000 cycles, 2 200 of them waiting for exactly these pieces).  Issue order of
+  // the prologue is then U(0) U(1) raw(0) raw(1) raw(2) instead of raw(0) {U(0) raw(1)} {U(1) raw(2)}; only the first
+  // counted wait of the K loop differs.  (Ring depth 3 only; the 4-slot diagnostic variant keeps the old order.)
+  const bool early_u = D == 3 && !(DK_WABL & 2);
+  const unsigned ubase = (unsigned)(tile_m * nst) * (unsigned)(W_STAGE * 4) + (unsigned)t256 * 16u;
+  if (early_u && dma_wave)
+  {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      if (s < nst)
+      {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          dma16(ur, u_lds + (unsigned)(s * W_STAGE) * 4u + (unsigned)j * 4096u,
+              ubase + (unsigned)s * (unsigned)(W_STAGE * 4) + (unsigned)j * 4096u);
+      }
+  }
+
   // ---- geometry of the strip: tile rows R0 .. Rlast (R = b * TH + ty), first tile column tx0 ----
   const int R0 = fdiv(n0, TW, p.inv_tiles_w);
   const int tx0 = n0 - R0 * TW;
@@ -470,7 +490,6 @@ __global__ void __launch_bounds__(512) conv3x3_wino_f32(const ConvArgs p)
     vdst = img_off(0, tl >> 5, tl & 31, c4);
   }
   const unsigned stage_x_bytes = (unsigned)(WCK * p.H * p.W) * 4u;
-  const unsigned ubase = (unsigned)(tile_m * nst) * (unsigned)(W_STAGE * 4) + (unsigned)t256 * 16u;
 
   f32x16 acc[8];
 #pragma unroll
@@ -479,7 +498,7 @@ __global__ void __launch_bounds__(512) conv3x3_wino_f32(const ConvArgs p)
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
   // zero the raw ring once (padding positions are never written again)
-  for (int i = tid; i < D * RAWF; i += 512) Rs[i] = 0.f;
+  for (int i = tid * 4; i < D * RAWF; i += 2048) *(float4*)(Rs + i) = make_float4(0.f, 0.f, 0.f, 0.f);
   WSTAMP(1);
   barrier_lds();
   WSTAMP(2);
@@ -546,7 +565,7 @@ __global__ void __launch_bounds__(512) conv3x3_wino_f32(const ConvArgs p)
     }
     else
     {
-      if constexpr (part == 4)
+      if constexpr (part == 4 || part == 8)   // (8: the column pass alone -- the prologue's second half of the waves)
       {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -557,38 +576,58 @@ __global__ void __launch_bounds__(512) conv3x3_wino_f32(const ConvArgs p)
           ww[i][3] = dd[i][1] - dd[i][3];
         }
       }
-      constexpr int i = part - 4;
-      float* const dst = Vnext + vdst + i * 4 * 256;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
+      if constexpr (part < 8)
       {
-        const float v = i == 0 ? ww[0][j] - ww[2][j] : i == 1 ? ww[1][j] + ww[2][j] : i == 2 ? ww[2][j] - ww[1][j] : ww[1][j] - ww[3][j];
-        dst[j * 256] = v;
+        constexpr int i = part - 4;
+        float* const dst = Vnext + vdst + i * 4 * 256;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+        {
+          const float v = i == 0 ? ww[0][j] - ww[2][j] : i == 1 ? ww[1][j] + ww[2][j] : i == 2 ? ww[2][j] - ww[1][j] : ww[1][j] - ww[3][j];
+          dst[j * 256] = v;
+        }
       }
     }
   };
 
   // ---- prologue: raw(0), B(0) .. B(D-2) in flight; V(0) from raw(0) ----------------------------
+  auto raw_count = [&](int s) { return s < nst ? cnt_r : 0; };
   if (dma_wave)
   {
-    issue_raw(0);
-    issue_bundle(0);
-    issue_bundle(1);
-    if (D > 3)
-      issue_bundle(2);
-    wait_vmcnt_n(bundle_count(0) + bundle_count(1) + (D > 3 ? bundle_count(2) : 0));
+    if (early_u)
+    {
+      issue_raw(0);
+      if (1 < nst) issue_raw(1);
+      if (2 < nst) issue_raw(2);
+      wait_vmcnt_n(raw_count(1) + raw_count(2));
+    }
+    else
+    {
+      issue_raw(0);
+      issue_bundle(0);
+      issue_bundle(1);
+      if (D > 3)
+        issue_bundle(2);
+      wait_vmcnt_n(bundle_count(0) + bundle_count(1) + (D > 3 ? bundle_count(2) : 0));
+    }
   }
   WSTAMP(3);
   barrier_lds();
   WSTAMP(4);
+  // V(0): every wave holds the (channel, tile) mapping of its 256-thread half, so the halves share the work -- waves
+  // 0-3 write V rows 0 and 1, waves 4-7 rows 2 and 3 (each reads the four raw rows and makes the column pass itself)
+  tslice(std::integral_constant<int, 0>(), Rs, Vs);
+  tslice(std::integral_constant<int, 1>(), Rs, Vs);
+  tslice(std::integral_constant<int, 2>(), Rs, Vs);
+  tslice(std::integral_constant<int, 3>(), Rs, Vs);
   if (xf_wave)
   {
-    tslice(std::integral_constant<int, 0>(), Rs, Vs);
-    tslice(std::integral_constant<int, 1>(), Rs, Vs);
-    tslice(std::integral_constant<int, 2>(), Rs, Vs);
-    tslice(std::integral_constant<int, 3>(), Rs, Vs);
     tslice(std::integral_constant<int, 4>(), Rs, Vs);
     tslice(std::integral_constant<int, 5>(), Rs, Vs);
+  }
+  else
+  {
+    tslice(std::integral_constant<int, 8>(), Rs, Vs);
     tslice(std::integral_constant<int, 6>(), Rs, Vs);
     tslice(std::integral_constant<int, 7>(), Rs, Vs);
   }
@@ -601,7 +640,7 @@ __global__ void __launch_bounds__(512) conv3x3_wino_f32(const ConvArgs p)
       // iteration t - 1 (V(t) complete; ring slots of U(t-1) and raw(t) free)
       WSTAMP(8 + 4 * t);      // arrived at the top of stage t (all MFMAs of t - 1 issued)
       if (dma_wave && !(DK_WABL & 8))
-        wait_vmcnt_n(bundle_count(t + 1) + (D > 3 ? bundle_count(t + 2) : 0));
+        wait_vmcnt_n((early_u && t == 0) ? raw_count(2) : bundle_count(t + 1) + (D > 3 ? bundle_count(t + 2) : 0));
       WSTAMP(9 + 4 * t);      // DMA of stage t landed (DMA waves)
       barrier_lds();
       WSTAMP(10 + 4 * t);     // released
@@ -685,7 +724,7 @@ __global__ void __launch_bounds__(512) conv3x3_wino_f32(const ConvArgs p)
     {
       WSTAMP(8 + 4 * t);
       if (dma_wave && !(DK_WABL & 8))
-        wait_vmcnt_n(bundle_count(t + 1) + (D > 3 ? bundle_count(t + 2) : 0));
+        wait_vmcnt_n((early_u && t == 0) ? raw_count(2) : bundle_count(t + 1) + (D > 3 ? bundle_count(t + 2) : 0));
       WSTAMP(9 + 4 * t);
       barrier_lds();
       WSTAMP(10 + 4 * t);

@@ -75,6 +75,20 @@ class DkNet:
         self.L.DkNetworkStageU8.restype = None
         self.L.DkNetworkStageU8(self.p, frames.ctypes.data, row_step)
 
+    def stage_float(self, x):
+        """DkNetworkStageFloat: float CHW frames of the NEXT batch: pinned copy + H2D on the staging stream (overlaps the
+        running forward); consumed by predict_staged()."""
+        x = np.ascontiguousarray(x, np.float32)
+        assert x.size == self.batch * self.inputs
+        self.L.DkNetworkStageFloat.argtypes = [C.c_void_p, C.c_void_p]
+        self.L.DkNetworkStageFloat.restype = None
+        self.L.DkNetworkStageFloat(self.p, x.ctypes.data)
+
+    def collect(self):
+        """Wait for the forward in flight and the D2H of its heads (NetworkSync)."""
+        self.L.NetworkSync.argtypes = [C.c_void_p]
+        self.L.NetworkSync(self.p)
+
     def predict_staged(self):
         self.L.DkNetworkPredictStaged.argtypes = [C.c_void_p]
         self.L.DkNetworkPredictStaged.restype = None

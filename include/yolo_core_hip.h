@@ -327,6 +327,14 @@ struct Network
   int u8_next, u8_staged; /* slot the next stage call fills; slot staged and not yet consumed (-1: none) + 1 */
   size_t u8_row_step;
   int u8_src_w, u8_src_h, u8_swap_rb; /* staged frames at another resolution (DkNetworkStageFrames): 0 = network size */
+  /* float frames staged ahead of the forward that consumes them (DkNetworkStageFloat) */
+  float* f32_stage_gpu;
+  float* f32_stage_pinned;
+  size_t f32_stage_floats;
+  void* f32_h2d_ev;      /* H2D of the staged batch finished (staging stream) */
+  void* f32_copy_ev;     /* the device copy stage -> input tensor finished (compute stream) */
+  int f32_copy_pending, f32_staged;
+  void* stage_stream;    /* H2D of staged inputs: a stream of its own, not queued behind the heads' D2H */
   float* delta_arena_gpu; /* train: every layer's delta_gpu lives in this one allocation (one memset per step) */
   size_t delta_arena_size;
   size_t delta_arena_zero; /* leading floats of the arena that must start a step at zero (the rest is overwritten before it is read) */
@@ -557,6 +565,11 @@ LIB_API void DkNetworkStageU8(Network* net, const unsigned char* frames_hwc, siz
 LIB_API void DkNetworkStageFrames(Network* net, const unsigned char* frames_hwc, int src_w, int src_h, size_t row_step,
     int swap_rb);
 LIB_API void DkNetworkPredictStaged(Network* net);
+/* float CHW frames (what NetworkPredict takes) staged AHEAD: pinned copy by a few host threads + H2D on the staging
+ * stream into a second device buffer, while the previous batch's forward runs; DkNetworkPredictStaged then copies it
+ * into the input tensor on the device (71 MB in ~30 us) and runs the forward.  Loop: PredictStaged(k); StageFloat(k + 1);
+ * read the results of k. */
+LIB_API void DkNetworkStageFloat(Network* net, const float* input);
 LIB_API float* DkLayerOutputGpu(Network* net, int i);
 LIB_API float* DkLayerHostPtr(Network* net, int i, int which); /* 1 weights 2 biases 3 scales 4 mean 5 var */
 /* Flattened detections of batch item b: per det [x,y,w,h,obj,prob[classes]] and

@@ -304,6 +304,30 @@ def test_staged_frames_resize_predict(gpu, weights):
     net.close()
 
 
+def test_staged_float_input_equals_network_predict(gpu, weights):
+    """DkNetworkStageFloat + DkNetworkPredictStaged (float frames staged ahead on the staging stream) == NetworkPredict on
+    the same frames, bitwise, over a loop that stages batch k + 1 while batch k runs; re-staging before a forward replaces
+    the staged batch."""
+    name = "yolov4-tiny"
+    net = netutil.DkNet(gpu, netutil.cfg_path(name), weights[name], batch=4)
+    heads = [i for i in range(net.n) if net.info(i)["type"] == O.YOLO]
+    xs = [synth.make_input(4, net.c, net.h, net.w, seed=70 + k) for k in range(4)]
+    want = []
+    for x in xs:
+        net.predict(x)
+        want.append([net.output(i).copy() for i in heads])
+    net.stage_float(xs[3])      # replaced by the next call before any forward consumes it
+    net.stage_float(xs[0])
+    for k in range(4):
+        net.predict_staged()
+        if k + 1 < 4:
+            net.stage_float(xs[k + 1])
+        net.collect()
+        for i, w in zip(heads, want[k]):
+            assert np.array_equal(net.output(i), w), "staged float batch %d, head %d differs from NetworkPredict" % (k, i)
+    net.close()
+
+
 def test_staged_u8_input_double_buffer(gpu, weights):
     """DkNetworkStageU8 / DkNetworkPredictStaged (the double-buffered input step): staging batch k+1 while the
     forward of batch k is in flight must not disturb batch k, over several alternations of the two slots."""
