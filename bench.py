@@ -57,13 +57,21 @@ BATCH_PER_GPU = 16
 
 
 def lib_sha16():
-    """First 16 hex digits of the sha256 of the loaded HIP library: ties a committed profile to the build it measured."""
+    """Identity of the HIP library build: first 16 hex digits of the sha256 over the SOURCES it is built from
+    (darknet_amd/csrc/**, include/*.h, sorted by path).  (The .so itself is not reproducible byte for byte -- two builds
+    of the same sources hash differently -- so a profile is tied to the sources; `make -q` says whether the shipped .so
+    is up to date with them.)"""
+    import glob
     import hashlib
-    import darknet_amd as dk
     h = hashlib.sha256()
-    with open(dk.LIB_PATH, "rb") as f:
-        for blk in iter(lambda: f.read(1 << 20), b""):
-            h.update(blk)
+    files = []
+    for pat in ("darknet_amd/csrc/**/*.hip", "darknet_amd/csrc/**/*.cpp", "darknet_amd/csrc/**/*.h", "darknet_amd/csrc/Makefile", "include/*.h"):
+        files += glob.glob(os.path.join(ROOT, pat), recursive=True)
+    for f in sorted(set(files)):
+        if os.sep + "build" + os.sep in f:
+            continue
+        h.update(os.path.relpath(f, ROOT).encode())
+        h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -82,8 +90,9 @@ def pmc_traffic_for(kernel, tag):
         try:
             run = json.load(open(os.path.join(os.path.dirname(f), "run.json")))
             if run.get("lib_sha16") != mine:
-                why = "the committed profile (%s) measured another build (lib_sha16 %s, loaded %s)" % (
-                    os.path.relpath(os.path.dirname(f), ROOT), run.get("lib_sha16"), mine)
+                if why.startswith("no committed"):
+                    why = "the newest committed profile (%s) measured another build (lib_sha16 %s, sources now %s)" % (
+                        os.path.relpath(os.path.dirname(f), ROOT), run.get("lib_sha16"), mine)
                 continue
             for r in json.load(open(f)):
                 if kernel in r["kernel"]:

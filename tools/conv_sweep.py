@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Dev tool (GPU box): time every compiled tile configuration of the implicit-GEMM
 conv kernel on each distinct conv shape of a cfg and print the table.
-usage: conv_sweep.py cfg/yolov4.cfg BATCH [iters]"""
+usage: conv_sweep.py cfg/yolov4.cfg BATCH [iters]
+DK_SWEEP_FILTER=k1|s2|k3s1 restricts the shapes; DK_SWEEP_TOGGLE=<exported int setter, e.g. dk_conv_set_lds_bias> measures
+every configuration with the switch at 0 and at 1 in the same process (A/B on one device, guide rule 24) and prints
+both best-per-layer totals."""
 import ctypes as C
 import json
 import os
@@ -46,6 +49,7 @@ def main():
     ncfg = L.dk_conv_force_config(-1)
     names = [L.dk_conv_config_name(i).decode() for i in range(ncfg)]
     rows = []
+    tot_off = [0.0]
     tot_best = tot_heur = 0.0
     tot_gflop = 0.0
     maxin = max(batch * k[0] * k[1] * k[2] for k in shapes)
@@ -66,6 +70,23 @@ def main():
             du = dk.DeviceArray(n=nu)
             L.dk_conv_wino_transform_weights(C.byref(d), wt.ptr, du.ptr, None)
             L.dk_conv_wino_register(wt.ptr, du.ptr)
+        toggle = os.environ.get("DK_SWEEP_TOGGLE")
+        times_off = []
+        if toggle:
+            getattr(L, toggle)(0)
+            for cfgi in range(ncfg):
+                L.dk_conv_force_config(cfgi)
+                L.dk_conv_forward(C.byref(d), dx.ptr, wt.ptr, bs.ptr, dy.ptr, None, None, None)
+                L.dk_profile_enable(1)
+                for _ in range(iters):
+                    L.dk_conv_forward(C.byref(d), dx.ptr, wt.ptr, bs.ptr, dy.ptr, None, None, None)
+                out = (C.c_double * (3 * 256))()
+                L.dk_profile_read(out, 256)
+                L.dk_profile_enable(0)
+                ms = sum(out[(cfgi * 4 + v) * 3 + 2] for v in range(4)) / iters
+                times_off.append(ms if ms > 0 else float("inf"))
+            getattr(L, toggle)(1)
+            tot_off[0] += min(times_off) * len(idxs)
         times = []
         for cfgi in range(ncfg):
             L.dk_conv_force_config(cfgi)
@@ -92,6 +113,8 @@ def main():
         print("L%-4d x%-2d c%-4d %3dx%-3d n%-4d k%d s%d  GF %7.2f | " % (idxs[0], cnt, c, h, w, n, size, stride, gf) +
               " ".join("%6.3f" % t for t in times) + " | best %d (%5.1f TF) heur %d (%5.1f TF)" %
               (best, gf / times[best], heur, gf / times[heur]), flush=True)
+        if toggle:
+            print("      %s: off best %.3f ms -> on best %.3f ms (%+.1f %%)" % (toggle, min(times_off), times[best], 100 * (times[best] / min(times_off) - 1)), flush=True)
         if du is not None:
             L.dk_conv_wino_register(wt.ptr, None)
             du.free()
@@ -100,6 +123,8 @@ def main():
     print("configs:", names)
     print("total conv GFLOP %.1f  best-per-layer %.3f ms (%.1f TF)  heuristic %.3f ms (%.1f TF)" %
           (tot_gflop, tot_best, tot_gflop / tot_best, tot_heur, tot_gflop / tot_heur))
+    if os.environ.get("DK_SWEEP_TOGGLE"):
+        print("%s: best-per-layer off %.3f ms -> on %.3f ms" % (os.environ["DK_SWEEP_TOGGLE"], tot_off[0], tot_best))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "conv_sweep_%s_b%d.json" % (os.path.basename(cfg), batch)), "w") as f:
         json.dump(dict(names=names, rows=rows), f)

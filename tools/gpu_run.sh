@@ -6,7 +6,8 @@
 #   smoke                               __graft_entry__.smoke()
 #   bench[:<bench.py args>]             default bench line (bench.json / bench.err), timed
 #   train[:<bench_train.py args>]       tools/bench_train.py
-#   sweep:<cfg>+<batch>[+<filter>]      tools/conv_sweep.py (every configuration on every conv shape; filter e.g. k3s1)
+#   sweep:<cfg>+<batch>[+<filter>[+<toggle>]]   tools/conv_sweep.py (every configuration on every conv shape; filter e.g. k3s1;
+#                                       toggle = an exported int setter measured at 0 and 1 in one process)
 #   stamps:<b>+<c>+<h>+<w>+<n>[+<config>+<act>[+res]]   tools/wino_stamps.py on a -DDK_WSTAMP build (tools/build_wstamp.sh first)
 #   bn                                  tools/bn_bench.py
 #   profiles[:<tag>]                    tools/make_profiles.sh gpurun_out/<name>/<tag> (rocprofv3 stats + PMC passes of bench.py)
@@ -28,7 +29,7 @@ for step in "$@"; do
     bench) ( time timeout -k 10 580 python bench.py $arg > $O/bench.json 2> $O/bench.err ) 2> $O/bench_time.txt; rc=$?
       grep real $O/bench_time.txt; tail -c 600 $O/bench.json ;;
     train) timeout -k 10 580 python tools/bench_train.py $arg > $O/train.json 2> $O/train.err; rc=$?; tail -c 600 $O/train.json ;;
-    sweep) set -- $arg; DK_SWEEP_FILTER=$3 timeout -k 10 900 python tools/conv_sweep.py cfg/$1.cfg $2 10 > $O/sweep.log 2>&1; rc=$?; tail -3 $O/sweep.log | cut -c1-300 ;;
+    sweep) set -- $arg; DK_SWEEP_FILTER=$3 DK_SWEEP_TOGGLE=$4 timeout -k 10 900 python tools/conv_sweep.py cfg/$1.cfg $2 10 > $O/sweep.log 2>&1; rc=$?; grep -v "^L\|^configs" $O/sweep.log | tail -60 | cut -c1-200 ;;
     stamps) DK_LIB=$R/build_abl/libdk_wstamp.so timeout -k 10 200 python tools/wino_stamps.py $arg >> $O/stamps.txt 2>&1; rc=$?; tail -20 $O/stamps.txt ;;
     bn) timeout -k 10 300 python tools/bn_bench.py 20 > $O/bn_bench.txt 2>&1; rc=$?; cat $O/bn_bench.txt ;;
     profiles) bash tools/make_profiles.sh $O/${arg:-c3} > $O/profiles.log 2>&1; rc=$?; tail -12 $O/profiles.log ;;
