@@ -63,6 +63,22 @@
       __syncthreads();    \
   } while (0)
 
+// Diagnostic build -DDK_GSTAMP=1 (tools/build_stamp.sh; never the shipped library): lane 0 of every wave of the first
+// 512 workgroups stamps s_memtime at the phase boundaries into g_gstamp (read back with dk_gather_stamps_read).
+#ifndef DK_GSTAMP
+#define DK_GSTAMP 0
+#endif
+#if DK_GSTAMP
+__device__ long long g_gstamp[512 * 16 * 8];
+#define GSTAMP(idx)                                                                                     \
+  do {                                                                                                  \
+    if (blockIdx.x < 512 && (threadIdx.x & 63) == 0)                                                    \
+      g_gstamp[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 8 + (idx)] = (long long)__builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define GSTAMP(idx)
+#endif
+
 // AVEC: weights rows are read as float4 (needs K % 4 == 0).
 // BVEC: 1x1 / stride 1 / pad 0 / OHW % 4 == 0: the B tile is a plain strided
 //       matrix, read as float4 along n and written to LDS with ds_write_b128.
@@ -108,6 +124,7 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
   int g, tile_m, tile_n;
   if (!conv_block_tile(p, g, tile_m, tile_n))
     return;
+  GSTAMP(0);
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
 
@@ -409,6 +426,7 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
     }
   };
 
+  GSTAMP(1);   // index arithmetic done
   if (nkt > 0)
   {
   if (PF == 1)
@@ -416,6 +434,7 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
     load_tile(k0_of(0), I0{});
     store_tile(lds, I0{});
     DK_BARRIER();
+    GSTAMP(2);   // first tile in LDS
     for (int kt = 0; kt < nkt; ++kt)
     {
       const bool more = (kt + 1) < nkt;
@@ -455,6 +474,7 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
   }
   }
 
+  GSTAMP(3);   // K loop done
   if (DK_ABL & 1)
   {
     // keep the accumulators alive without the epilogue
@@ -470,7 +490,22 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
     return;
   }
   conv_epilogue<BM, BN, WM, WN, TM, TN>(p, acc, m0, n0, g, wm, wn, l31, lh);
+  GSTAMP(4);   // every store issued
+#if DK_GSTAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  GSTAMP(5);   // stores drained
+#endif
 }
+
+#if DK_GSTAMP
+extern "C" __attribute__((visibility("default"))) int dk_gather_stamps_read(long long* dst, int n)
+{
+  const int have = 512 * 16 * 8;
+  CHECK_HIP(hipDeviceSynchronize());
+  CHECK_HIP(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_gstamp), sizeof(long long) * (n < have ? n : have)));
+  return have;
+}
+#endif
 
 // --------------------------------------------------------------------------
 // host side: plans (tap table + tile choice), dispatch, profiling
