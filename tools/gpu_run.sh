@@ -12,6 +12,7 @@
 #   gstamps:<b>+<c>+<h>+<w>+<n>+<size>+<stride>+<pad>+<act>+<config>   tools/gather_stamps.py (tools/build_stamp.sh conv_igemm DK_GSTAMP first)
 #   act:<b>+<c>+<h>+<w>+<n>+<config>     tools/act_cost.py (LINEAR / LEAKY / MISH epilogue of one 1x1 shape)
 #   bn                                  tools/bn_bench.py
+#   tool:<script>[+args]                 python tools/<script>.py args  (output <script>.txt)
 #   profiles[:<tag>]                    tools/make_profiles.sh gpurun_out/<name>/<tag> (rocprofv3 stats + PMC passes of bench.py)
 # A failing step stops the run (no GPU step is started after a failed or timed-out one).
 R=${GRAFT_REPO_ROOT:-$PWD}
@@ -36,6 +37,7 @@ for step in "$@"; do
     gstamps) DK_LIB=$R/build_abl/libdk_conv_igemm_stamp.so timeout -k 10 200 python tools/gather_stamps.py $arg >> $O/gstamps.txt 2>&1; rc=$?; tail -12 $O/gstamps.txt ;;
     act) timeout -k 10 200 python tools/act_cost.py $arg >> $O/act_cost.txt 2>&1; rc=$?; tail -2 $O/act_cost.txt ;;
     bn) timeout -k 10 300 python tools/bn_bench.py 20 > $O/bn_bench.txt 2>&1; rc=$?; cat $O/bn_bench.txt ;;
+    tool) set -- $arg; t=$1; shift; timeout -k 10 300 python tools/$t.py "$@" >> $O/$t.txt 2>&1; rc=$?; tail -12 $O/$t.txt ;;
     profiles) bash tools/make_profiles.sh $O/${arg:-c3} > $O/profiles.log 2>&1; rc=$?; tail -12 $O/profiles.log ;;
     *) echo "unknown step $kind"; rc=2 ;;
   esac
