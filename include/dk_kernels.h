@@ -236,13 +236,6 @@ DK_API int dk_transpose_weights(const float* w, float* wt, int M, int C, int siz
 DK_API int dk_transpose_weights_flip(const float* w, float* wt, int M, int C, int size, void* stream);
 /* 1 when tile / kernel configuration cfg (dk_conv_config_name) can run the layer d */
 DK_API int dk_conv_config_can_run(const DkConvDesc* d, int cfg);
-/* The yolov4 stem in one launch (conv_stem.hip): d0 = 3x3/s1/p1 with c <= 4 -> 32 filters, d1 = 3x3/s2/p1 32 -> a
- * multiple of 64 filters on d0's output (even h, w).  Replaces two ForwardConvolutionalLayer calls
- * (src/convolutional_layer.cpp:1128-1305) whose intermediate tensor nothing else reads; the result is bitwise the
- * two-call one.  Biases are the folded ones (inference); out_ctot as in dk_conv_forward's strided form (0: dense). */
-DK_API int dk_conv_stem_applicable(const DkConvDesc* d0, const DkConvDesc* d1);
-DK_API int dk_conv_stem_forward(const DkConvDesc* d0, const DkConvDesc* d1, const float* x, const float* w0, const float* b0,
-    const float* w1, const float* b1, float* y, int out_ctot, void* stream);
 /* 1: weight gradients and BN channel sums through ordered workspaces instead of atomics (two runs of a training step
  * with the same kernel choices are then bitwise equal); 0: atomics (default, faster); -1: follow DK_DETERMINISTIC */
 DK_API void dk_set_deterministic(int on);

@@ -464,60 +464,3 @@ def test_conv_winograd_on_caller_owned_memory_without_slack(gpu):
         L.dk_conv_wino_register(dw.ptr, None)
         hip.hipFree(raw)
 
-
-STEM_CASES = [
-    # batch, c0, h, w, n1, act0, act1
-    (2, 3, 64, 96, 64, O.MISH, O.MISH),        # yolov4's stem, small
-    (1, 3, 38, 70, 64, O.MISH, O.LEAKY),       # ragged: 35 output columns, 19 rows -> partial tiles in both directions
-    (2, 4, 32, 32, 128, O.LEAKY, O.LINEAR),    # four input channels, two filter tiles
-    (3, 1, 6, 130, 64, O.LOGISTIC, O.MISH),    # one channel; three column tiles, 3 output rows
-]
-
-
-@pytest.mark.parametrize("case", STEM_CASES, ids=lambda c: "x".join(str(v) for v in c))
-def test_conv_stem_equals_the_two_calls_it_replaces(gpu, case):
-    """dk_conv_stem_forward (conv_stem.hip; src/convolutional_layer.cpp:1128-1305 twice): layers 0 and 1 of the yolov4
-    family in one launch == dk_conv_forward(layer 0) -> dk_conv_forward(layer 1) BITWISE (the VALU fmaf chain of layer 0
-    and the stride-2 patch MFMA of layer 1 keep the k-ascending order of the library's kernels), and within the usual
-    tolerance of the oracle's two convolutions; also into a channel slice of a wider tensor (out_ctot)."""
-    batch, c0, h, w, n1, act0, act1 = case
-    rng = np.random.default_rng(util.seed_of(case))
-    x = rng.uniform(0, 1, (batch, c0, h, w)).astype(np.float32)
-    w0 = (rng.uniform(-1, 1, (32, c0, 3, 3)) * np.sqrt(2.0 / (9 * c0))).astype(np.float32)
-    b0 = rng.uniform(-.5, .5, 32).astype(np.float32)
-    w1 = (rng.uniform(-1, 1, (n1, 32, 3, 3)) * np.sqrt(2.0 / (9 * 32))).astype(np.float32)
-    b1 = rng.uniform(-.5, .5, n1).astype(np.float32)
-    L = gpu.lib()
-    VP = C.c_void_p
-    L.dk_conv_stem_applicable.argtypes = [VP, VP]
-    L.dk_conv_stem_forward.argtypes = [VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, VP]
-    d0 = gpu.DkConvDesc(batch, c0, h, w, 32, 1, 3, 1, 1, 1, 1, act0)
-    d1 = gpu.DkConvDesc(batch, 32, h, w, n1, 1, 3, 2, 2, 1, 1, act1)
-    assert L.dk_conv_stem_applicable(C.byref(d0), C.byref(d1)) == 1
-    dx, dw0, db0, dw1, db1 = (gpu.DeviceArray(a) for a in (x, w0, b0, w1, b1))
-    oh, ow = h // 2, w // 2
-    dmid = gpu.DeviceArray(n=batch * 32 * h * w)
-    dtwo = gpu.DeviceArray(n=batch * n1 * oh * ow)
-    assert L.dk_conv_forward(C.byref(d0), dx.ptr, dw0.ptr, db0.ptr, dmid.ptr, None, None, None) == 0
-    assert L.dk_conv_forward(C.byref(d1), dmid.ptr, dw1.ptr, db1.ptr, dtwo.ptr, None, None, None) == 0
-    two = dtwo.numpy().reshape(batch, n1, oh, ow)
-    done = gpu.DeviceArray(n=batch * n1 * oh * ow)
-    assert L.dk_conv_stem_forward(C.byref(d0), C.byref(d1), dx.ptr, dw0.ptr, db0.ptr, dw1.ptr, db1.ptr, done.ptr, 0, None) == 0
-    one = done.numpy().reshape(batch, n1, oh, ow)
-    assert np.array_equal(one.view(np.uint32), two.view(np.uint32)), \
-        "fused stem differs from the two calls: max |d| = %g" % np.abs(one - two).max()
-    mid, _ = orc_conv(x, w0, b0, batch, c0, h, w, 32, 3, 1, 1, act0)
-    ref, _ = orc_conv(mid, w1, b1, batch, 32, h, w, n1, 3, 2, 1, act1)
-    util.assert_close(one, ref.reshape(one.shape), "fused stem vs oracle")
-    # into channels [0, n1) of a tensor with n1 + 7 channels, the rest untouched
-    ctot = n1 + 7
-    wide = np.full((batch, ctot, oh, ow), 3.25, np.float32)
-    dwide = gpu.DeviceArray(wide)
-    assert L.dk_conv_stem_forward(C.byref(d0), C.byref(d1), dx.ptr, dw0.ptr, db0.ptr, dw1.ptr, db1.ptr, dwide.ptr, ctot, None) == 0
-    got = dwide.numpy().reshape(wide.shape)
-    assert np.array_equal(got[:, :n1], two) and np.all(got[:, n1:] == 3.25)
-    # not the stem: a stride-1 second layer, or a 5-channel input
-    d1b = gpu.DkConvDesc(batch, 32, h, w, n1, 1, 3, 1, 1, 1, 1, act1)
-    assert L.dk_conv_stem_applicable(C.byref(d0), C.byref(d1b)) == 0
-    d0b = gpu.DkConvDesc(batch, 5, h, w, 32, 1, 3, 1, 1, 1, 1, act0)
-    assert L.dk_conv_stem_applicable(C.byref(d0b), C.byref(d1)) == 0
