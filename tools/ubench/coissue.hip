@@ -155,14 +155,16 @@ void mixrun(const float* g, float* out, int iters)
       NW / 4, NF, ms / 5, ms / 5 * 2.4e6 / (iters * 16.0));
 }
 
-// In-wave cost table: per fp32 MFMA, NF copies of ONE kind of filler instruction in program order (1 wave / SIMD).
-// kind: 0 v_fma_f32, 1 ds_read_b32, 2 ds_read_b64, 3 ds_read_b128, 4 s_add (SALU), 5 v_pk_fma_f32, 6 ds_write_b32, 7 v_exp_f32
-template <int KIND, int NF>
-__global__ void __launch_bounds__(256) kfill(const float* __restrict__ g, float* out, int iters)
+// In-wave cost table: per fp32 MFMA, NF copies of ONE kind of filler instruction in program order (NW/4 waves per SIMD).
+// Everything in the loop body is volatile inline asm: the optimiser can neither merge, pack nor move the fillers.
+// kind: 0 v_fma_f32, 1 ds_read_b32, 2 ds_read_b64, 3 ds_read_b128, 4 s_add (SALU), 5 v_pk_fma_f32, 6 ds_write_b32, 7 v_exp_f32,
+//       8 v_add_u32
+template <int KIND, int NF, int NW>
+__global__ void __launch_bounds__(NW * 64) kfill(const float* __restrict__ g, float* out, int iters)
 {
   __shared__ __attribute__((aligned(16))) float hog[30000];
   const int tid = threadIdx.x, lane = tid & 63;
-  for (int i = tid; i < 8192; i += 256) hog[i] = g[i & 4095];
+  for (int i = tid; i < 8192; i += NW * 64) hog[i] = g[i & 4095];
   __syncthreads();
   float s = 0.f;
   f32x16 acc[2];
@@ -173,43 +175,50 @@ __global__ void __launch_bounds__(256) kfill(const float* __restrict__ g, float*
   const float m = g[lane + 200], c = g[lane + 400];
   f32x2 p2[4];
   for (int i = 0; i < 4; ++i) p2[i] = f32x2{f[i], f[i + 4]};
+  const f32x2 m2 = f32x2{m, m}, c2 = f32x2{c, c};
+  f32x4 q4[4];
+  for (int i = 0; i < 4; ++i) q4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   int sreg = iters;
-  const float* lp = hog + tid * 4;
+  unsigned u[8];
+  for (int i = 0; i < 8; ++i) u[i] = tid + i;
+  // conflict-free LDS addresses: consecutive lanes -> consecutive 4 / 8 / 16 bytes
+  const unsigned l4 = (unsigned)(size_t)(hog + tid), l8 = (unsigned)(size_t)(hog + tid * 2), l16 = (unsigned)(size_t)(hog + tid * 4);
   for (int it = 0; it < iters; ++it)
 #pragma unroll
     for (int r = 0; r < 16; ++r)
     {
-      acc[r & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[r & 1], 0, 0, 0);
+      if (r & 1) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[1]) : "v"(a), "v"(b));
+      else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[0]) : "v"(a), "v"(b));
 #pragma unroll
       for (int i = 0; i < NF; ++i)
       {
-        if (KIND == 0) f[i & 7] = __builtin_fmaf(f[i & 7], m, c);
-        else if (KIND == 1) { float v; asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"((unsigned)(size_t)lp), "i"(i * 4)); f[i & 7] = v; }
-        else if (KIND == 2) { f32x2 v; asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"((unsigned)(size_t)lp), "i"(i * 8)); p2[i & 3] = v; }
-        else if (KIND == 3) { f32x4 v; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"((unsigned)(size_t)lp), "i"(i * 16)); f[i & 7] = v[0]; }
+        if (KIND == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[i & 7]) : "v"(m), "v"(c));
+        else if (KIND == 1) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f[i & 7]) : "v"(l4), "i"((i & 7) * 2048));
+        else if (KIND == 2) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(p2[i & 3]) : "v"(l8), "i"((i & 3) * 4096));
+        else if (KIND == 3) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q4[i & 3]) : "v"(l16), "i"((i & 3) * 8192));
         else if (KIND == 4) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sreg));
-        else if (KIND == 5) p2[i & 3] = __builtin_elementwise_fma(p2[i & 3], f32x2{m, m}, f32x2{c, c});
-        else if (KIND == 6) asm volatile("ds_write_b32 %0, %1 offset:%2" : : "v"((unsigned)(size_t)lp), "v"(f[i & 7]), "i"(i * 4) : "memory");
-        else if (KIND == 7) f[i & 7] = __builtin_amdgcn_exp2f(f[i & 7]);
+        else if (KIND == 5) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p2[i & 3]) : "v"(m2), "v"(c2));
+        else if (KIND == 6) asm volatile("ds_write_b32 %0, %1 offset:%2" : : "v"(l4), "v"(f[i & 7]), "i"((i & 7) * 2048) : "memory");
+        else if (KIND == 7) asm volatile("v_exp_f32 %0, %0" : "+v"(f[i & 7]));
+        else if (KIND == 8) asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[i & 7]) : "v"(tid));
       }
       if (KIND >= 1 && KIND <= 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
     }
   for (int i = 0; i < 2; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
-  for (int i = 0; i < 8; ++i) s += f[i];
-  for (int i = 0; i < 4; ++i) s += p2[i][0] + p2[i][1];
+  for (int i = 0; i < 8; ++i) s += f[i] + (float)u[i];
+  for (int i = 0; i < 4; ++i) s += p2[i][0] + p2[i][1] + q4[i][0];
   out[blockIdx.x * 512 + tid] = s + (float)sreg;
 }
 
-template <int KIND, int NF>
+template <int KIND, int NF, int NW>
 float fillrun(const float* g, float* out, int iters)
 {
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-  hipLaunchKernelGGL((kfill<KIND, NF>), dim3(256), dim3(256), 0, 0, g, out, iters);
+  hipLaunchKernelGGL((kfill<KIND, NF, NW>), dim3(256), dim3(NW * 64), 0, 0, g, out, iters);
   CHECK(hipDeviceSynchronize());
   CHECK(hipEventRecord(e0, 0));
-  for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((kfill<KIND, NF>), dim3(256), dim3(256), 0, 0, g, out, iters);
+  for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((kfill<KIND, NF, NW>), dim3(256), dim3(NW * 64), 0, 0, g, out, iters);
   CHECK(hipEventRecord(e1, 0));
   CHECK(hipEventSynchronize(e1));
   float ms = 0;
@@ -217,13 +226,13 @@ float fillrun(const float* g, float* out, int iters)
   return ms / 5 * 2.4e6 / (iters * 16.0);   // cycles per MFMA slot at 2.4 GHz
 }
 
-template <int KIND>
+template <int KIND, int NW>
 void fillrow(const char* name, const float* g, float* out)
 {
-  const float c0 = fillrun<KIND, 0>(g, out, 2000), c2 = fillrun<KIND, 2>(g, out, 2000), c4 = fillrun<KIND, 4>(g, out, 2000),
-              c8 = fillrun<KIND, 8>(g, out, 2000);
-  printf("beside one f32 32x32x2 MFMA (%.1f cyc bare): %-14s x2 %+6.1f  x4 %+6.1f  x8 %+6.1f cycles  (%.1f each at x8)\n", c0, name, c2 - c0, c4 - c0,
-      c8 - c0, (c8 - c0) / 8);
+  const float c0 = fillrun<KIND, 0, NW>(g, out, 2000), c2 = fillrun<KIND, 2, NW>(g, out, 2000), c4 = fillrun<KIND, 4, NW>(g, out, 2000),
+              c8 = fillrun<KIND, 8, NW>(g, out, 2000), c16 = fillrun<KIND, 16, NW>(g, out, 2000);
+  printf("%d wave/SIMD, per f32 32x32x2 MFMA (%.1f cyc bare): %-13s x2 %+6.1f  x4 %+6.1f  x8 %+6.1f  x16 %+6.1f cycles\n", NW / 4, c0, name,
+      c2 - c0, c4 - c0, c8 - c0, c16 - c0);
 }
 
 template <int V, int M>
@@ -266,11 +275,9 @@ int main()
   trio<1, 2>("pk_fma_f32", "mfma f16 32x32x16", g, out, iters);
   trio<2, 2>("fma_f32", "mfma f16 32x32x16", g, out, iters);
   trio<3, 2>("int add/xor", "mfma f16 32x32x16", g, out, iters);
-  mixrun<0, 4, 0>(g, out, 2000); mixrun<4, 4, 0>(g, out, 2000); mixrun<8, 4, 0>(g, out, 2000); mixrun<16, 4, 0>(g, out, 2000);
-  mixrun<24, 4, 0>(g, out, 2000); mixrun<32, 4, 0>(g, out, 2000);
-  mixrun<0, 8, 0>(g, out, 2000); mixrun<8, 8, 0>(g, out, 2000); mixrun<16, 8, 0>(g, out, 2000);
-  mixrun<0, 4, 1>(g, out, 2000); mixrun<4, 4, 1>(g, out, 2000); mixrun<8, 4, 1>(g, out, 2000); mixrun<16, 4, 1>(g, out, 2000);
-  fillrow<0>("v_fma_f32", g, out); fillrow<5>("v_pk_fma_f32", g, out); fillrow<7>("v_exp_f32", g, out); fillrow<4>("s_add_u32", g, out);
-  fillrow<1>("ds_read_b32", g, out); fillrow<2>("ds_read_b64", g, out); fillrow<3>("ds_read_b128", g, out); fillrow<6>("ds_write_b32", g, out);
+  fillrow<0, 4>("v_fma_f32", g, out); fillrow<8, 4>("v_add_u32", g, out); fillrow<5, 4>("v_pk_fma_f32", g, out); fillrow<7, 4>("v_exp_f32", g, out);
+  fillrow<4, 4>("s_add_u32", g, out); fillrow<1, 4>("ds_read_b32", g, out); fillrow<2, 4>("ds_read_b64", g, out);
+  fillrow<3, 4>("ds_read_b128", g, out); fillrow<6, 4>("ds_write_b32", g, out);
+  fillrow<0, 8>("v_fma_f32", g, out); fillrow<3, 8>("ds_read_b128", g, out);
   return 0;
 }
