@@ -335,6 +335,224 @@ __global__ void __launch_bounds__(T) conv_wgrad_f32(const WgradArgs p)
     emit(std::false_type{});
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// conv_wgrad3_f32 -- the weight gradient of 3x3 / stride 1 / pad 1 layers (round 3).
+// The gather kernel above fetches every tap of every pixel as its own 4-byte load (16 per thread and 32-pixel stage, each
+// with its own padding test) and re-reads x nine times, once per tap tile; it sits at 50-54 TFLOP/s on these layers.
+// Here a workgroup owns 128 filters x (32 channels x ALL 9 taps) of dW and walks output-row segments of SEG pixels:
+//   * per stage the delta segment [128][SEG] and the raw input patch [32 ch][3 rows][SEG + halo] are staged with row-wise
+//     vector loads (VW floats each: 16 / 8 / 4 bytes by the row alignment W allows; padding = the buffer descriptor's
+//     out-of-range zero), double-buffered, one barrier per stage, the next stage's loads in flight during the MFMAs;
+//   * wave w owns filters 32 w .. 32 w + 31 and nine 32x32 accumulators, one per tap: the B operand of tap (kh, kw) is the
+//     raw patch at the lane's channel + a compile-time offset (conv3x3_direct.hip's formulation), so the nine taps cost
+//     nine LDS reads of data that was loaded ONCE -- no im2col, no per-tap gather, no index arithmetic in the loop;
+//   * one two-dword LDS read per operand feeds two MFMAs (lanes 0-31 take pixels 4j, 4j+1, lanes 32-63 pixels 4j+2, 4j+3:
+//     the contraction pairs are (4j, 4j+2), (4j+1, 4j+3) -- the pixel sum has no prescribed order, as above); row pitches
+//     = 2 mod 4 make 32 lanes x 2 dwords hit 64 distinct banks;
+//   * epilogue: the tile goes through LDS so that a filter's 32 x 9 gradients leave as 288 CONSECUTIVE floats of
+//     dW[m][c][kh][kw] (coalesced float atomics, or plain stores into the pixel split's slice in deterministic mode).
+// 10 LDS reads + ~2 global loads per 18 MFMAs instead of the gather kernel's 5 vector instructions per MFMA
+// (vector and LDS instructions are not hidden behind fp32 MFMAs on this part).
+template <int SEG, int VW>
+__global__ void __launch_bounds__(T, 2) conv_wgrad3_f32(const WgradArgs p)
+{
+  constexpr int LSA = SEG + 2;                            // delta row pitch (= 2 mod 4)
+  constexpr int HALO = VW;                                // input columns staged before the segment's first pixel
+  constexpr int XCH = (HALO + SEG + 1 + VW - 1) / VW;     // VW-float pieces per input row
+  constexpr int XW = XCH * VW;
+  constexpr int RP = (XW % 4 == 2) ? XW : XW + 2;         // input row pitch (= 2 mod 4)
+  constexpr int CP = 3 * RP;                              // channel pitch (= 2 mod 4 too)
+  constexpr int A_FL = 128 * LSA, B_FL = 32 * CP, STAGE = A_FL + B_FL;
+  // piece -> thread: a thread keeps ONE piece column and walks rows with a uniform step, so a piece's address is
+  // (per-thread offset) + (pass * uniform step): one add per load, an immediate in the LDS store, no per-piece registers
+  constexpr int ACH = SEG / VW;                           // pieces per delta row
+  constexpr int ARP = T / ACH;                            // delta rows per pass
+  constexpr int PA = (128 + ARP - 1) / ARP;               // passes
+  constexpr int XRP = (T / XCH) / 3 * 3;                  // input rows (channel x kh) per pass: a multiple of 3 keeps kh fixed
+  constexpr int PB = (96 + XRP - 1) / XRP;
+  static_assert(SEG % 4 == 0 && LSA % 4 == 2 && RP % 4 == 2, "pitches");
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 stages: [128][LSA] delta, [32][3][RP] input
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  int id = blockIdx.x;
+  const int split = id % p.nsplit;
+  id /= p.nsplit;
+  const int tile_c = id % p.tiles_k;
+  const int tile_m = id / p.tiles_k;
+  const int m0 = tile_m * 128, c0 = tile_c * 32;
+  const int nseg = (p.OW + SEG - 1) / SEG;
+  const int nstages = p.N / p.OW * nseg;                  // N = images * OH * OW
+  const int st_begin = split * p.stages_per_split;
+  int st_end = st_begin + p.stages_per_split;
+  if (st_end > nstages)
+    st_end = nstages;
+
+  __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc((void*)p.delta, 0, p.d_bytes, 0x00020000);
+
+  // ---- the thread's piece column and first row ---------------------------------------------------------------------
+  const int a_row0 = tid / ACH, a_ch = tid - a_row0 * ACH;
+  const bool a_thr = tid < ARP * ACH;
+  const unsigned a_off0 = (unsigned)((m0 + a_row0) * p.OHW + a_ch * VW) * 4u;     // relative to (image, row oy, pixel ox0)
+  const int a_lds0 = a_row0 * LSA + a_ch * VW;
+  const int b_rr0 = tid / XCH, b_xc = tid - b_rr0 * XCH;
+  const bool b_thr = tid < XRP * XCH;
+  const int b_c0 = b_rr0 / 3, b_kh = b_rr0 - b_c0 * 3;
+  const unsigned b_off0 = (unsigned)(((c0 + b_c0) * p.H + b_kh - 1) * p.W + b_xc * VW - HALO) * 4u;
+  const int b_lds0 = A_FL + b_c0 * CP + b_kh * RP + b_xc * VW;
+  const unsigned a_step = (unsigned)(ARP * p.OHW) * 4u, b_step = (unsigned)((XRP / 3) * p.H * p.W) * 4u;
+
+  float ra[PA * VW], rb[PB * VW];
+  auto load_piece = [&](__amdgpu_buffer_rsrc_t r, unsigned voff, float* dst) {
+    if (VW == 4)
+    {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0);
+      dst[0] = __uint_as_float(v.x); dst[1] = __uint_as_float(v.y); dst[2] = __uint_as_float(v.z); dst[3] = __uint_as_float(v.w);
+    }
+    else if (VW == 2)
+    {
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, 0, 0);
+      dst[0] = __uint_as_float(v.x); dst[1] = __uint_as_float(v.y);
+    }
+    else
+      dst[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, 0, 0));
+  };
+  auto load_stage = [&](int s) {
+    const int seg = s % nseg;
+    const int t = s / nseg;
+    const int oy = t % p.OH, b = t / p.OH;
+    const int ox0 = seg * SEG;
+    const unsigned abase = (unsigned)(b * p.Mtot * p.OHW + oy * p.OW + ox0) * 4u;
+    const unsigned bbase = (unsigned)((b * p.Ctot * p.H + oy) * p.W + ox0) * 4u;
+    // padding and ragged ends: an out-of-range offset, the load returns zeros (the uniform part only moves it further out;
+    // everything goes through the VECTOR offset: the bounds check does not see a scalar offset)
+    const bool aok = a_thr && ox0 + a_ch * VW < p.OW;
+    const bool bok = b_thr && (unsigned)(oy + b_kh - 1) < (unsigned)p.H && (unsigned)(ox0 + b_xc * VW - HALO) < (unsigned)p.W;
+    const unsigned av = aok ? a_off0 : OOB, bv = bok ? b_off0 : OOB;
+#pragma unroll
+    for (int j = 0; j < PA; ++j)
+      load_piece(dr, (((j + 1) * ARP <= 128 || a_row0 + j * ARP < 128) ? av : OOB) + (abase + (unsigned)j * a_step), ra + j * VW);
+#pragma unroll
+    for (int j = 0; j < PB; ++j)
+    {
+      // b_off0 is "negative" (mod 2^32) for the row above / the columns left of the segment: only the SUM is an offset.
+      // The asm hides the addition from the instruction selector, which would otherwise fold the uniform half into the
+      // load's scalar offset -- and the bounds check looks at the vector half alone (measured: every (c0 + 0, kh = 0) row zero)
+      unsigned voff = (((j + 1) * XRP <= 96 || b_rr0 + j * XRP < 96) ? bv : OOB) + (bbase + (unsigned)j * b_step);
+      asm volatile("" : "+v"(voff));
+      load_piece(xr, voff, rb + j * VW);
+    }
+  };
+  auto store_stage = [&](float* stg) {
+    if (a_thr)
+    {
+#pragma unroll
+      for (int j = 0; j < PA; ++j)
+        if ((j + 1) * ARP <= 128 || a_row0 + j * ARP < 128)
+        {
+#pragma unroll
+          for (int e = 0; e < VW; e += 2)
+          {
+            if (VW >= 2) *(float2*)(stg + a_lds0 + j * (ARP * LSA) + e) = float2{ra[j * VW + e], ra[j * VW + e + 1]};
+            else stg[a_lds0 + j * (ARP * LSA)] = ra[j];
+          }
+        }
+    }
+    if (b_thr)
+    {
+#pragma unroll
+      for (int j = 0; j < PB; ++j)
+        if ((j + 1) * XRP <= 96 || b_rr0 + j * XRP < 96)
+        {
+#pragma unroll
+          for (int e = 0; e < VW; e += 2)
+          {
+            if (VW >= 2) *(float2*)(stg + b_lds0 + j * ((XRP / 3) * CP) + e) = float2{rb[j * VW + e], rb[j * VW + e + 1]};
+            else stg[b_lds0 + j * ((XRP / 3) * CP)] = rb[j];
+          }
+        }
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  if (st_begin < st_end)
+  {
+    load_stage(st_begin);
+    store_stage(lds);
+    __syncthreads();
+    for (int st = st_begin; st < st_end; ++st)
+    {
+      const float* cur = lds + ((st - st_begin) & 1) * STAGE;
+      const bool more = st + 1 < st_end;
+      if (more)
+        load_stage(st + 1);
+      const float* ap = cur + (wave * 32 + l31) * LSA + 2 * lh;
+      const float* bp = cur + A_FL + l31 * CP + 2 * lh + HALO - 1;
+#pragma unroll
+      for (int j = 0; j < SEG / 4; ++j)
+      {
+        const float2 a = *(const float2*)(ap + 4 * j);
+        float bx[9], by[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+        {
+          bx[t] = bp[(t / 3) * RP + (t % 3) + 4 * j];
+          by[t] = bp[(t / 3) * RP + (t % 3) + 4 * j + 1];
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bx[t], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, by[t], acc[t], 0, 0, 0);
+      }
+      if (more)
+        store_stage(lds + ((st + 1 - st_begin) & 1) * STAGE);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: 16 filters of the wave at a time through LDS, so that a filter's 288 gradients leave consecutively ----
+  constexpr int EP = 289;                                 // row pitch of the transposition buffer (host: wgrad3_lds_bytes)
+  float* const eb = lds + wave * (16 * EP);
+  float* const dst = p.part ? p.part + (size_t)split * p.part_stride : p.dw;
+  const bool det = p.part != nullptr;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+  {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r8 = 0; r8 < 8; ++r8)
+      {
+        const int r = 8 * h + r8;
+        eb[((r & 3) + 8 * ((r >> 2) & 1) + 4 * lh) * EP + l31 * 9 + t] = acc[t][r];   // C/D: row (r&3)+8(r>>2)+4 lh, col l31
+      }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const size_t mrow = (size_t)(m0 + wave * 32 + 16 * h);
+    for (int e = lane; e < 16 * 288; e += 64)
+    {
+      const int lr = e / 288, col = e - lr * 288;
+      const float v = eb[lr * EP + col];
+      float* const q = dst + ((mrow + lr) * p.C + c0) * 9 + col;
+      if (det)
+        *q = v;
+      else
+        atomicAdd(q, v);
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
 // deterministic mode: dW[i] += sum over the pixel splits, ascending, of their partial tiles (tap-major partials are
 // un-permuted on the way, as wgrad_fold_kernel does for the atomic form)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, size_t stride, float* __restrict__ dw,
@@ -472,6 +690,30 @@ static bool wgrad_knob_tmaj()
   return g_force_tmaj != -2 ? g_force_tmaj != 0 : env_on;
 }
 
+// conv_wgrad3_f32 takes 3x3 / stride 1 / pad 1 layers with one group, channels a multiple of 32, filters a multiple of 128
+bool dk_wgrad3_applicable(const DkConvDesc* d)
+{
+  return d && d->size == 3 && d->stride_x == 1 && d->stride_y == 1 && d->pad == 1 && d->dilation == 1 && d->groups == 1 &&
+         d->c % 32 == 0 && d->n % 128 == 0 && d->w >= 4;
+}
+namespace
+{
+template <int SEG, int VW>
+constexpr int wgrad3_lds_bytes()
+{
+  constexpr int XCH = (VW + SEG + 1 + VW - 1) / VW, XW = XCH * VW, RP = (XW % 4 == 2) ? XW : XW + 2;
+  constexpr int stage2 = 2 * (128 * (SEG + 2) + 32 * 3 * RP), ep = 4 * 16 * 289;
+  return (stage2 > ep ? stage2 : ep) * (int)sizeof(float);
+}
+template <int SEG, int VW>
+void wgrad3_launch(const WgradArgs& a, long long nblk, hipStream_t st)
+{
+  constexpr int lds_bytes = wgrad3_lds_bytes<SEG, VW>();
+  dk_set_max_dynamic_lds((const void*)conv_wgrad3_f32<SEG, VW>, lds_bytes);
+  hipLaunchKernelGGL((conv_wgrad3_f32<SEG, VW>), dim3((unsigned)nblk), dim3(T), lds_bytes, st, a);
+}
+}  // namespace
+
 extern "C" int dk_conv_backward_weights(const DkConvDesc* d, const float* x, const float* delta,
     float* weight_updates, void* stream)
 {
@@ -520,8 +762,64 @@ int dk_conv_backward_weights_cfg(const DkConvDesc* d, const float* x, const floa
     a.N = nb * OH * OW;
     a.size = d->size; a.stride_x = d->stride_x; a.stride_y = d->stride_y;
     a.pad = pad; a.dil = d->dilation;
-    int ci = (M > 64 ? 0 : 1) + (K > 64 ? 0 : 2);  // 128/64 rows x 128/64 taps
     const int knob = wgrad_knob_tile();
+    // configuration 4: the row-staged 3x3 kernel (the default where it applies; a forced tile 0..3 keeps the gather kernel)
+    const bool pick3 = cfg_override == 4 || (cfg_override < 0 && (knob == 4 || knob == -1));
+    if (pick3 && dk_wgrad3_applicable(d))
+    {
+      const int seg = OW <= 20 ? 20 : 40;
+      const int nseg = (OW + seg - 1) / seg;
+      const long long nst = (long long)nb * OH * nseg;
+      a.tiles_m = M / 128;
+      a.tiles_k = C / 32;
+      a.groups = 1;
+      const long long tiles3 = (long long)a.tiles_m * a.tiles_k;
+      static const long long target = getenv("DK_WGRAD3_BLOCKS") ? atoll(getenv("DK_WGRAD3_BLOCKS")) : 512;
+      long long want = (target + tiles3 - 1) / tiles3;
+      if (want < 1) want = 1;
+      if (want > nst) want = nst;
+      a.stages_per_split = (int)((nst + want - 1) / want);
+      a.nsplit = (int)((nst + a.stages_per_split - 1) / a.stages_per_split);
+      const long long nblk = tiles3 * a.nsplit;
+      const bool det = dk_deterministic();
+      a.part = nullptr;
+      a.part_stride = 0;
+      if (det)
+      {
+        a.part_stride = (unsigned long long)d->n * K;
+        a.part = wgrad_part_workspace((size_t)a.nsplit * a.part_stride, st);
+      }
+      const bool al16 = (((uintptr_t)a.x | (uintptr_t)a.delta) & 15) == 0, al8 = (((uintptr_t)a.x | (uintptr_t)a.delta) & 7) == 0;
+      const int vw = (d->w % 4 == 0 && al16 && g_force_avec != 0) ? 4 : (d->w % 2 == 0 && al8 && g_force_avec != 0) ? 2 : 1;
+      DkProfScope prof;
+      dk_prof_begin(prof, st);
+      if (seg == 20)
+        wgrad3_launch<20, 1>(a, nblk, st);
+      else if (vw == 4)
+        wgrad3_launch<40, 4>(a, nblk, st);
+      else if (vw == 2)
+        wgrad3_launch<40, 2>(a, nblk, st);
+      else
+        wgrad3_launch<40, 1>(a, nblk, st);
+      CHECK_HIP(hipPeekAtLastError());
+      if (prof.e0)
+      {
+        char nm[96];
+        snprintf(nm, sizeof(nm), "conv_wgrad3_f32<%d, %d>", seg, seg == 20 ? 1 : vw);
+        dk_prof_end(prof, st, dk_prof_named_slot(nm), 2.0 * (double)M * K * (double)a.N / 1e9);
+      }
+      if (det)
+      {
+        const size_t total = (size_t)d->n * K;
+        unsigned gb = (unsigned)((total + 255) / 256);
+        if (gb > 8192u) gb = 8192u;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gb), dim3(256), 0, st, a.part, a.nsplit, (size_t)a.part_stride,
+            weight_updates, C, 9, total, 0);
+        CHECK_HIP(hipPeekAtLastError());
+      }
+      continue;
+    }
+    int ci = (M > 64 ? 0 : 1) + (K > 64 ? 0 : 2);  // 128/64 rows x 128/64 taps
     if (knob <= -11)
       ci |= -10 - knob;   // DK_WGRAD_TILE=1/2/3: 64x128 / 128x64 / 64x64 tiles (tuning experiments)
     // 3x3 layers with 64 (not 128) channels per tap: 64-tap tiles keep the tap-major path available
@@ -529,7 +827,7 @@ int dk_conv_backward_weights_cfg(const DkConvDesc* d, const float* x, const floa
       ci |= 2;
     if (cfg_override >= 0 && cfg_override < 4)
       ci = cfg_override;
-    else if (knob >= 0 && knob < 4)
+    else if (knob >= 0 && knob < 4 && cfg_override < 0)
       ci = knob;
     const WgradCfg& c = g_wcfg[ci];
     const int BM = 64 * c.tm, BKO = 64 * c.tk;

@@ -29,6 +29,8 @@ bool dk_conv_dgrad_tapmajor(const DkConvDesc* d);
 // number of gather (implicit-GEMM) tile configurations: indices [0, n) of the configuration table
 int dk_conv_num_gather_configs();
 // dk_conv_backward_weights with an explicit tile shape (0..3: 128x128, 64x128, 128x64, 64x64 rows x taps; < 0: heuristic)
+// 1 when configuration 4 of dk_conv_backward_weights_cfg (conv_wgrad3_f32) takes the layer
+bool dk_wgrad3_applicable(const DkConvDesc* d);
 int dk_conv_backward_weights_cfg(const DkConvDesc* d, const float* x, const float* delta, float* weight_updates,
     void* stream, int cfg);
 int dk_conv_forward_half_strided(const DkConvDesc* d, const float* x, const float* weights,

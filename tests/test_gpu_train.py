@@ -107,6 +107,8 @@ TRAIN_VARIANT_SHAPES = [
     (2, 64, 19, 19, 128, 3),      # 64 channels per tap: only the 64-tap tiles are tap-major
     (2, 256, 38, 38, 128, 1),
     (3, 24, 13, 17, 40, 3),       # ragged everything: no tap-major tile, no 16-byte delta loads
+    (2, 32, 23, 45, 128, 3),      # odd width above one segment: the row-staged 3x3 kernel's 4-byte pieces, two segments
+    (1, 64, 10, 86, 256, 3),      # width = 2 mod 4, three segments (the last 6 pixels wide), 8-byte pieces
 ]
 
 
@@ -184,6 +186,25 @@ def test_every_training_kernel_variant_vs_oracle(gpu, case):
                         util.assert_close(ddw.numpy().reshape(wt.shape), ref_dw,
                                           "wgrad %s tile %d tap-major %d avec %d deterministic %d" % (case, tile, tmaj, avec, det),
                                           atol_rms=wg_atol)
+                        ddw.free()
+        # the row-staged 3x3 kernel (tile 4; the default where it applies): piece width by the row alignment, atomics / ordered
+        if size == 3 and c % 32 == 0 and n % 128 == 0:
+            G.dk_train_force(1, -1)
+            for avec in (0, -1):
+                for det in (0, 1):
+                    for tile in (4, -1):
+                        G.dk_train_force(0, tile)
+                        G.dk_train_force(2, avec)
+                        G.dk_set_deterministic(det)
+                        ddw = gpu.DeviceArray(dw0)
+                        assert G.dk_conv_backward_weights(C.byref(d), dx.ptr, dd.ptr, ddw.ptr, None) == 0
+                        ran = [k for k in _ran_kernels(gpu.lib()) if k.startswith("conv_wgrad")]
+                        seg = 20 if w <= 20 else 40
+                        vw = 1 if (seg == 20 or avec == 0) else 4 if w % 4 == 0 else 2 if w % 2 == 0 else 1
+                        assert ran == ["conv_wgrad3_f32<%d, %d>" % (seg, vw)], ran
+                        seen.add((ran[0], det))
+                        util.assert_close(ddw.numpy().reshape(wt.shape), ref_dw,
+                                          "wgrad3 %s avec %d deterministic %d" % (case, avec, det), atol_rms=wg_atol)
                         ddw.free()
     finally:
         for k in range(3):
