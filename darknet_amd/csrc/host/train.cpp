@@ -476,7 +476,11 @@ void BackwardConvolutionalLayerGpu(layer* l, NetworkState state)
     const bool tuned_before = l->train_plan[2] != 0 && (!state.delta || l->train_plan[1] != 0);
     if (!tuned_before)
       DkJoinWgradStream(net);
-    const int wcfg = train_choice(l, 2, d, scratch_dw ? std::vector<int>{-1, 0, 1, 2, 3} : std::vector<int>{-1}, -1,
+    // (-1 is the row-staged 3x3 kernel where it applies, 5 its one-workgroup-per-CU split)
+    std::vector<int> wcands = {-1, 0, 1, 2, 3};
+    if (dk_wgrad3_applicable(&d))
+      wcands.push_back(5);
+    const int wcfg = train_choice(l, 2, d, scratch_dw ? wcands : std::vector<int>{-1}, -1,
         [&](int c) {
           if (dk_conv_backward_weights_cfg(&d, state.input, l->delta_gpu, scratch_dw, st, c))
             error("weight gradient (timing) failed");

@@ -53,6 +53,7 @@ struct WgradArgs
   // ([split][the dW index space], plain stores) and wgrad_reduce_kernel adds the slices in ascending split order
   float* part;
   unsigned long long part_stride;
+  int abl;   // DK_WGRAD3_ABL timing diagnostics (results are garbage): 1 no epilogue stores, 2 no staging after the first stage, 4 no MFMAs
 };
 
 constexpr unsigned OOB = 0x80000000u;
@@ -493,31 +494,46 @@ __global__ void __launch_bounds__(T, 2) conv_wgrad3_f32(const WgradArgs p)
     {
       const float* cur = lds + ((st - st_begin) & 1) * STAGE;
       const bool more = st + 1 < st_end;
-      if (more)
+      if (more && !(p.abl & 2))
         load_stage(st + 1);
       const float* ap = cur + (wave * 32 + l31) * LSA + 2 * lh;
       const float* bp = cur + A_FL + l31 * CP + 2 * lh + HALO - 1;
+      // operands of pixel group j: the delta pair and, per input row kh, the FOUR consecutive columns the three kw taps
+      // of the lane's two pixels touch (tap kw of pixel 0 = column kw, of pixel 1 = column kw + 1): 7 LDS reads per 18
+      // MFMAs.  Group j + 1 is fetched before group j is multiplied and pinned there (sched_barrier): with one or two
+      // waves per SIMD nothing else covers the LDS latency -- the compiler's own placement (reads one MFMA ahead of their
+      // use) left the loop at 56 % MFMA-busy.
+      float2 av[2];
+      float bv[2][3][4];
+      auto fetch = [&](int j, int buf) {
+        av[buf] = *(const float2*)(ap + 4 * j);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bv[buf][kh][e] = bp[kh * RP + 4 * j + e];
+      };
+      fetch(0, 0);
+      if (!(p.abl & 4))
 #pragma unroll
       for (int j = 0; j < SEG / 4; ++j)
       {
-        const float2 a = *(const float2*)(ap + 4 * j);
-        float bx[9], by[9];
+        const int cb = j & 1;
+        if (j + 1 < SEG / 4)
+          fetch(j + 1, cb ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
-        {
-          bx[t] = bp[(t / 3) * RP + (t % 3) + 4 * j];
-          by[t] = bp[(t / 3) * RP + (t % 3) + 4 * j + 1];
-        }
+        for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb].x, bv[cb][t / 3][t % 3], acc[t], 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bx[t], acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, by[t], acc[t], 0, 0, 0);
+        for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb].y, bv[cb][t / 3][t % 3 + 1], acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      if (more)
+      if (more && !(p.abl & 2))
         store_stage(lds + ((st + 1 - st_begin) & 1) * STAGE);
       __syncthreads();
     }
   }
+  if (p.abl & 1)
+    return;
 
   // ---- epilogue: 16 filters of the wave at a time through LDS, so that a filter's 288 gradients leave consecutively ----
   constexpr int EP = 289;                                 // row pitch of the transposition buffer (host: wgrad3_lds_bytes)
@@ -751,6 +767,7 @@ int dk_conv_backward_weights_cfg(const DkConvDesc* d, const float* x, const floa
   {
     const int nb = (d->batch - b0 < chunk) ? d->batch - b0 : chunk;
     WgradArgs a;
+    a.abl = 0;
     a.x = x + (size_t)b0 * in_img;
     a.delta = delta + (size_t)b0 * out_img;
     a.dw = weight_updates;
@@ -763,18 +780,25 @@ int dk_conv_backward_weights_cfg(const DkConvDesc* d, const float* x, const floa
     a.size = d->size; a.stride_x = d->stride_x; a.stride_y = d->stride_y;
     a.pad = pad; a.dil = d->dilation;
     const int knob = wgrad_knob_tile();
-    // configuration 4: the row-staged 3x3 kernel (the default where it applies; a forced tile 0..3 keeps the gather kernel)
-    const bool pick3 = cfg_override == 4 || (cfg_override < 0 && (knob == 4 || knob == -1));
+    // configurations 4 / 5: the row-staged 3x3 kernel with ~2 / ~1 workgroups per CU (4 is the default where the kernel
+    // applies; a forced tile 0..3 keeps the gather kernel).  The pixel splits are what the epilogue pays for -- every split
+    // adds its whole 128 x 288 tile to dW (ablation, [256->256 38x38] b8: 0.046 of 0.183 ms) -- so fewer, longer workgroups
+    // win on the layers with few tiles and lose where the second workgroup per CU was covering latency; first-step timing picks.
+    const int want3 = cfg_override >= 0 ? cfg_override : knob;
+    const bool pick3 = want3 == 4 || want3 == 5 || (cfg_override < 0 && knob == -1);
     if (pick3 && dk_wgrad3_applicable(d))
     {
       const int seg = OW <= 20 ? 20 : 40;
       const int nseg = (OW + seg - 1) / seg;
       const long long nst = (long long)nb * OH * nseg;
+      static const int abl3 = getenv("DK_WGRAD3_ABL") ? atoi(getenv("DK_WGRAD3_ABL")) : 0;
+      a.abl = abl3;
       a.tiles_m = M / 128;
       a.tiles_k = C / 32;
       a.groups = 1;
       const long long tiles3 = (long long)a.tiles_m * a.tiles_k;
-      static const long long target = getenv("DK_WGRAD3_BLOCKS") ? atoll(getenv("DK_WGRAD3_BLOCKS")) : 512;
+      static const long long target_env = getenv("DK_WGRAD3_BLOCKS") ? atoll(getenv("DK_WGRAD3_BLOCKS")) : 0;
+      const long long target = target_env > 0 ? target_env : want3 == 5 ? 256 : 512;
       long long want = (target + tiles3 - 1) / tiles3;
       if (want < 1) want = 1;
       if (want > nst) want = nst;

@@ -192,7 +192,7 @@ def test_every_training_kernel_variant_vs_oracle(gpu, case):
             G.dk_train_force(1, -1)
             for avec in (0, -1):
                 for det in (0, 1):
-                    for tile in (4, -1):
+                    for tile in (4, 5, -1):
                         G.dk_train_force(0, tile)
                         G.dk_train_force(2, avec)
                         G.dk_set_deterministic(det)

@@ -25,7 +25,7 @@ def train_tune_summary(dk, net):
             if c < -1:
                 continue
             if kind == 2:
-                key = {-1: "heuristic", 0: "128x128", 1: "64x128", 2: "128x64", 3: "64x64"}[c]
+                key = {-1: "heuristic", 0: "128x128", 1: "64x128", 2: "128x64", 3: "64x64", 4: "rows3x3", 5: "rows3x3_1wg"}.get(c, str(c))
             else:
                 key = "heuristic" if c < 0 else (L.dk_conv_config_name(c) or b"?").decode()
             hist[key] = hist.get(key, 0) + 1

@@ -56,7 +56,7 @@ def main():
         r = rows.setdefault(k, [int(c), float(gf), 0.0])
         r[2] += float(ms) / steps
     kinds = ("fwd", "dgrad", "wgrad")
-    wname = {-1: "heuristic", 0: "128x128", 1: "64x128", 2: "128x64", 3: "64x64"}
+    wname = {-1: "heuristic", 0: "128x128", 1: "64x128", 2: "128x64", 3: "64x64", 4: "rows3x3", 5: "rows3x3_1wg"}
     tot = [0.0, 0.0, 0.0]
     print("layer  shape                                 kind   config                      GF      ms     TF")
     for (li, kind), (c, gf, ms) in sorted(rows.items()):
