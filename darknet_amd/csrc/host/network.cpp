@@ -540,6 +540,7 @@ void ForwardNetworkGpu(Network* net, NetworkState state)
 {
   state.workspace = net->workspace;
   hipStream_t st = get_cuda_stream();
+  int pulled = 0;
   if (state.train)
     DkTrainPrepRun(net);
   if (state.train && net->delta_arena_gpu && net->delta_arena_zero)
@@ -567,8 +568,27 @@ void ForwardNetworkGpu(Network* net, NetworkState state)
     }
     if (net->wait_stream)
       CHECK_HIP(hipStreamSynchronize(st));
+    // yolo heads -> pinned host memory on the copy stream AS SOON AS the head exists (the reference pulls them
+    // asynchronously inside ForwardYoloLayerGpu, yolo_layer.cpp:854-858): yolov4's 76x76 head is 94 of the 123 MB a batch
+    // of 16 sends back and is final a fifth of the forward before its end, so most of the PCIe time runs under the
+    // remaining layers.  Inside a stream capture the event pair makes the copies a parallel branch of the graph.
+    if (net->pull_in_forward && !state.train && (l->type == YOLO || l->type == GAUSSIAN_YOLO) && pulled < 8)
+    {
+      hipStream_t cs = get_cuda_memcpy_stream();
+      hipEvent_t ev = (hipEvent_t)net->head_ev[pulled++];
+      CHECK_HIP(hipEventRecord(ev, st));
+      CHECK_HIP(hipStreamWaitEvent(cs, ev, 0));
+      CHECK_HIP(hipMemcpyAsync(l->output, l->output_gpu, (size_t)l->batch * l->outputs * sizeof(float), hipMemcpyDeviceToHost, cs));
+    }
     if (l->output_gpu)
       state.input = DkLayerOut(l);
+  }
+  if (pulled)
+  {
+    // join: the compute stream is finished when the heads are on the host (and may rewrite them afterwards)
+    hipStream_t cs = get_cuda_memcpy_stream();
+    CHECK_HIP(hipEventRecord((hipEvent_t)net->copy_done_ev, cs));
+    CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)net->copy_done_ev, 0));
   }
 }
 
@@ -582,6 +602,12 @@ static void ensure_events(Network* net)
     CHECK_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
     net->fwd_done_ev = a;
     net->copy_done_ev = b;
+    for (int k = 0; k < 8; ++k)
+    {
+      hipEvent_t e;
+      CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      net->head_ev[k] = e;
+    }
   }
 }
 
@@ -602,17 +628,31 @@ void NetworkPredictDevice(Network* net, float* input_gpu)
   state.input = input_gpu ? input_gpu : net->input_state_gpu;
   state.train = 0;
 
-  // the previous call's head copies must finish before the heads are rewritten
-  if (net->copy_pending)
-  {
-    CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)net->copy_done_ev, 0));
-    net->copy_pending = 0;
-  }
+  // (the head copies of the previous call were joined into the compute stream by that call's forward)
+  net->copy_pending = 0;
+  net->pull_in_forward = net_pull_heads(net) ? 1 : 0;
+  int yolo_heads = 0;
+  size_t head_bytes = 0;
+  for (int i = 0; i < net->n; ++i)
+    if (net->layers[i].type == YOLO || net->layers[i].type == GAUSSIAN_YOLO)
+    {
+      ++yolo_heads;
+      head_bytes += (size_t)net->layers[i].batch * net->layers[i].outputs * sizeof(float);
+    }
+  const bool late_pull = net->pull_in_forward && yolo_heads > 8;   // more heads than events: the old form, after the forward
+  if (late_pull)
+    net->pull_in_forward = 0;
 
+  // Large heads go out under PLAIN launches: a graph replay runs its copy branch after the kernels (measured, yolov4
+  // 608 b16, frames in / heads out: 809 images/s replayed, 919 launched, 930 without the heads), and at the batch sizes
+  // where the heads are tens of MB the launches hide behind the kernels anyway.
   const bool can_graph = net_graph(net) && !net->benchmark_layers && !net->wait_stream &&
-                         !dk_profile_is_on() && state.input == net->input_state_gpu;
+                         !dk_profile_is_on() && state.input == net->input_state_gpu &&
+                         !(net->pull_in_forward && head_bytes > ((size_t)8 << 20));
   if (can_graph)
   {
+    if (net->graph_exec && net->graph_pull != net->pull_in_forward)
+      DkInvalidateGraph(net);   // captured with / without the head copies
     if (!net->graph_exec)
     {
       hipGraph_t graph = nullptr;
@@ -623,16 +663,16 @@ void NetworkPredictDevice(Network* net, float* input_gpu)
       CHECK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
       CHECK_HIP(hipGraphDestroy(graph));
       net->graph_exec = exec;
+      net->graph_pull = net->pull_in_forward;
     }
     CHECK_HIP(hipGraphLaunch((hipGraphExec_t)net->graph_exec, st));
   }
   else
     ForwardNetworkGpu(net, state);
+  net->pull_in_forward = 0;
 
-  if (net_pull_heads(net))
+  if (late_pull)
   {
-    // yolo heads -> pinned host memory on the copy stream (the reference pulls
-    // them asynchronously inside ForwardYoloLayerGpu, yolo_layer.cpp:854-858)
     hipStream_t cs = get_cuda_memcpy_stream();
     CHECK_HIP(hipEventRecord((hipEvent_t)net->fwd_done_ev, st));
     CHECK_HIP(hipStreamWaitEvent(cs, (hipEvent_t)net->fwd_done_ev, 0));
@@ -644,7 +684,7 @@ void NetworkPredictDevice(Network* net, float* input_gpu)
             (size_t)l->batch * l->outputs * sizeof(float), hipMemcpyDeviceToHost, cs));
     }
     CHECK_HIP(hipEventRecord((hipEvent_t)net->copy_done_ev, cs));
-    net->copy_pending = 1;
+    CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)net->copy_done_ev, 0));
   }
 }
 
@@ -1410,6 +1450,8 @@ void FreeNetwork(Network* net)
     DkFreeDpState(net);
     if (net->fwd_done_ev) (void)hipEventDestroy((hipEvent_t)net->fwd_done_ev);
     if (net->copy_done_ev) (void)hipEventDestroy((hipEvent_t)net->copy_done_ev);
+    for (int k = 0; k < 8; ++k)
+      if (net->head_ev[k]) (void)hipEventDestroy((hipEvent_t)net->head_ev[k]);
   }
   free(net->layers);
   free(net->steps);
