@@ -120,7 +120,7 @@ def main():
                           "config": {"workload": "%s.cfg %dx%d batch=%d/GPU train step (forward with batch statistics, host yolo loss, "
                                                  "backward, gradient all-reduce, SGD)" % (a.cfg, net.w, net.h, a.batch)},
                           "grad_bucket_mfloats": tr.bucket.numel() / 1e6, "roofline": roofline,
-                          "train_tune": train_tune_summary(dk, net)}))
+                          "train_tune": train_tune_summary(dk, net), "lib_sha16": __import__("bench").lib_sha16()}))
     net.close(); ctx.close()
 
 
