@@ -337,7 +337,7 @@ __global__ void __launch_bounds__(T) conv_wgrad_f32(const WgradArgs p)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// conv_wgrad3_f32 -- the weight gradient of 3x3 / stride 1 / pad 1 layers (round 3).
+// conv_wgrad3_f32 -- the weight gradient of 3x3 / pad 1 layers of stride S = 1 or 2 (round 3).
 // The gather kernel above fetches every tap of every pixel as its own 4-byte load (16 per thread and 32-pixel stage, each
 // with its own padding test) and re-reads x nine times, once per tap tile; it sits at 50-54 TFLOP/s on these layers.
 // Here a workgroup owns 128 filters x (32 channels x ALL 9 taps) of dW and walks output-row segments of SEG pixels:
@@ -354,14 +354,16 @@ __global__ void __launch_bounds__(T) conv_wgrad_f32(const WgradArgs p)
 //     dW[m][c][kh][kw] (coalesced float atomics, or plain stores into the pixel split's slice in deterministic mode).
 // 10 LDS reads + ~2 global loads per 18 MFMAs instead of the gather kernel's 5 vector instructions per MFMA
 // (vector and LDS instructions are not hidden behind fp32 MFMAs on this part).
-template <int SEG, int VW>
+// S = 2 (the down-sampling layers): the lane's two pixels are two input columns apart, a tap is still a compile-time offset;
+// the segment is 20 output pixels there (40 input columns + halo keep two workgroups per CU).
+template <int SEG, int VW, int S>
 __global__ void __launch_bounds__(T, 2) conv_wgrad3_f32(const WgradArgs p)
 {
   constexpr int LSA = SEG + 2;                            // delta row pitch (= 2 mod 4)
   constexpr int HALO = VW;                                // input columns staged before the segment's first pixel
-  constexpr int XCH = (HALO + SEG + 1 + VW - 1) / VW;     // VW-float pieces per input row
+  constexpr int XCH = (HALO + S * (SEG - 1) + 2 + VW - 1) / VW;   // VW-float pieces per input row
   constexpr int XW = XCH * VW;
-  constexpr int RP = (XW % 4 == 2) ? XW : XW + 2;         // input row pitch (= 2 mod 4)
+  constexpr int RP = XW + (6 - XW % 4) % 4;               // input row pitch (= 2 mod 4)
   constexpr int CP = 3 * RP;                              // channel pitch (= 2 mod 4 too)
   constexpr int A_FL = 128 * LSA, B_FL = 32 * CP, STAGE = A_FL + B_FL;
   // piece -> thread: a thread keeps ONE piece column and walks rows with a uniform step, so a piece's address is
@@ -402,7 +404,7 @@ __global__ void __launch_bounds__(T, 2) conv_wgrad3_f32(const WgradArgs p)
   const int b_rr0 = tid / XCH, b_xc = tid - b_rr0 * XCH;
   const bool b_thr = tid < XRP * XCH;
   const int b_c0 = b_rr0 / 3, b_kh = b_rr0 - b_c0 * 3;
-  const unsigned b_off0 = (unsigned)(((c0 + b_c0) * p.H + b_kh - 1) * p.W + b_xc * VW - HALO) * 4u;
+  const unsigned b_off0 = (unsigned)(((c0 + b_c0) * p.H + b_kh - 1) * p.W + b_xc * VW - HALO) * 4u;   // relative to (row S oy, column S ox0)
   const int b_lds0 = A_FL + b_c0 * CP + b_kh * RP + b_xc * VW;
   const unsigned a_step = (unsigned)(ARP * p.OHW) * 4u, b_step = (unsigned)((XRP / 3) * p.H * p.W) * 4u;
 
@@ -428,11 +430,11 @@ __global__ void __launch_bounds__(T, 2) conv_wgrad3_f32(const WgradArgs p)
     const int oy = t % p.OH, b = t / p.OH;
     const int ox0 = seg * SEG;
     const unsigned abase = (unsigned)(b * p.Mtot * p.OHW + oy * p.OW + ox0) * 4u;
-    const unsigned bbase = (unsigned)((b * p.Ctot * p.H + oy) * p.W + ox0) * 4u;
+    const unsigned bbase = (unsigned)((b * p.Ctot * p.H + S * oy) * p.W + S * ox0) * 4u;
     // padding and ragged ends: an out-of-range offset, the load returns zeros (the uniform part only moves it further out;
     // everything goes through the VECTOR offset: the bounds check does not see a scalar offset)
     const bool aok = a_thr && ox0 + a_ch * VW < p.OW;
-    const bool bok = b_thr && (unsigned)(oy + b_kh - 1) < (unsigned)p.H && (unsigned)(ox0 + b_xc * VW - HALO) < (unsigned)p.W;
+    const bool bok = b_thr && (unsigned)(S * oy + b_kh - 1) < (unsigned)p.H && (unsigned)(S * ox0 + b_xc * VW - HALO) < (unsigned)p.W;
     const unsigned av = aok ? a_off0 : OOB, bv = bok ? b_off0 : OOB;
 #pragma unroll
     for (int j = 0; j < PA; ++j)
@@ -497,20 +499,20 @@ __global__ void __launch_bounds__(T, 2) conv_wgrad3_f32(const WgradArgs p)
       if (more && !(p.abl & 2))
         load_stage(st + 1);
       const float* ap = cur + (wave * 32 + l31) * LSA + 2 * lh;
-      const float* bp = cur + A_FL + l31 * CP + 2 * lh + HALO - 1;
-      // operands of pixel group j: the delta pair and, per input row kh, the FOUR consecutive columns the three kw taps
-      // of the lane's two pixels touch (tap kw of pixel 0 = column kw, of pixel 1 = column kw + 1): 7 LDS reads per 18
+      const float* bp = cur + A_FL + l31 * CP + S * 2 * lh + HALO - 1;
+      // operands of pixel group j: the delta pair and, per input row kh, the 3 + S consecutive columns the three kw taps
+      // of the lane's two pixels touch (tap kw of pixel 0 = column kw, of pixel 1 = column kw + S): 7 LDS reads per 18
       // MFMAs.  Group j + 1 is fetched before group j is multiplied and pinned there (sched_barrier): with one or two
       // waves per SIMD nothing else covers the LDS latency -- the compiler's own placement (reads one MFMA ahead of their
       // use) left the loop at 56 % MFMA-busy.
       float2 av[2];
-      float bv[2][3][4];
+      float bv[2][3][3 + S];
       auto fetch = [&](int j, int buf) {
         av[buf] = *(const float2*)(ap + 4 * j);
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) bv[buf][kh][e] = bp[kh * RP + 4 * j + e];
+          for (int e = 0; e < 3 + S; ++e) bv[buf][kh][e] = bp[kh * RP + S * 4 * j + e];
       };
       fetch(0, 0);
       if (!(p.abl & 4))
@@ -524,7 +526,7 @@ __global__ void __launch_bounds__(T, 2) conv_wgrad3_f32(const WgradArgs p)
 #pragma unroll
         for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb].x, bv[cb][t / 3][t % 3], acc[t], 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb].y, bv[cb][t / 3][t % 3 + 1], acc[t], 0, 0, 0);
+        for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb].y, bv[cb][t / 3][t % 3 + S], acc[t], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
       if (more && !(p.abl & 2))
@@ -706,27 +708,30 @@ static bool wgrad_knob_tmaj()
   return g_force_tmaj != -2 ? g_force_tmaj != 0 : env_on;
 }
 
-// conv_wgrad3_f32 takes 3x3 / stride 1 / pad 1 layers with one group, channels a multiple of 32, filters a multiple of 128
+// conv_wgrad3_f32 takes 3x3 / pad 1 layers of stride 1, or 2 on even maps, with one group, channels a multiple of 32,
+// filters a multiple of 128
 bool dk_wgrad3_applicable(const DkConvDesc* d)
 {
-  return d && d->size == 3 && d->stride_x == 1 && d->stride_y == 1 && d->pad == 1 && d->dilation == 1 && d->groups == 1 &&
+  const bool s1 = d && d->stride_x == 1 && d->stride_y == 1;
+  const bool s2 = d && d->stride_x == 2 && d->stride_y == 2 && d->h % 2 == 0 && d->w % 2 == 0;
+  return d && d->size == 3 && (s1 || s2) && d->pad == 1 && d->dilation == 1 && d->groups == 1 &&
          d->c % 32 == 0 && d->n % 128 == 0 && d->w >= 4;
 }
 namespace
 {
-template <int SEG, int VW>
+template <int SEG, int VW, int S>
 constexpr int wgrad3_lds_bytes()
 {
-  constexpr int XCH = (VW + SEG + 1 + VW - 1) / VW, XW = XCH * VW, RP = (XW % 4 == 2) ? XW : XW + 2;
+  constexpr int XCH = (VW + S * (SEG - 1) + 2 + VW - 1) / VW, XW = XCH * VW, RP = XW + (6 - XW % 4) % 4;
   constexpr int stage2 = 2 * (128 * (SEG + 2) + 32 * 3 * RP), ep = 4 * 16 * 289;
   return (stage2 > ep ? stage2 : ep) * (int)sizeof(float);
 }
-template <int SEG, int VW>
+template <int SEG, int VW, int S>
 void wgrad3_launch(const WgradArgs& a, long long nblk, hipStream_t st)
 {
-  constexpr int lds_bytes = wgrad3_lds_bytes<SEG, VW>();
-  dk_set_max_dynamic_lds((const void*)conv_wgrad3_f32<SEG, VW>, lds_bytes);
-  hipLaunchKernelGGL((conv_wgrad3_f32<SEG, VW>), dim3((unsigned)nblk), dim3(T), lds_bytes, st, a);
+  constexpr int lds_bytes = wgrad3_lds_bytes<SEG, VW, S>();
+  dk_set_max_dynamic_lds((const void*)conv_wgrad3_f32<SEG, VW, S>, lds_bytes);
+  hipLaunchKernelGGL((conv_wgrad3_f32<SEG, VW, S>), dim3((unsigned)nblk), dim3(T), lds_bytes, st, a);
 }
 }  // namespace
 
@@ -788,7 +793,8 @@ int dk_conv_backward_weights_cfg(const DkConvDesc* d, const float* x, const floa
     const bool pick3 = want3 == 4 || want3 == 5 || (cfg_override < 0 && knob == -1);
     if (pick3 && dk_wgrad3_applicable(d))
     {
-      const int seg = OW <= 20 ? 20 : 40;
+      const int S3 = d->stride_x;
+      const int seg = (OW <= 20 || S3 == 2) ? 20 : 40;
       const int nseg = (OW + seg - 1) / seg;
       const long long nst = (long long)nb * OH * nseg;
       static const int abl3 = getenv("DK_WGRAD3_ABL") ? atoi(getenv("DK_WGRAD3_ABL")) : 0;
@@ -814,22 +820,29 @@ int dk_conv_backward_weights_cfg(const DkConvDesc* d, const float* x, const floa
         a.part = wgrad_part_workspace((size_t)a.nsplit * a.part_stride, st);
       }
       const bool al16 = (((uintptr_t)a.x | (uintptr_t)a.delta) & 15) == 0, al8 = (((uintptr_t)a.x | (uintptr_t)a.delta) & 7) == 0;
-      const int vw = (d->w % 4 == 0 && al16 && g_force_avec != 0) ? 4 : (d->w % 2 == 0 && al8 && g_force_avec != 0) ? 2 : 1;
+      // (a piece must not straddle a row end of EITHER tensor: the delta rows are OW wide)
+      const int vw = (d->w % 4 == 0 && OW % 4 == 0 && al16 && g_force_avec != 0) ? 4 : (d->w % 2 == 0 && OW % 2 == 0 && al8 && g_force_avec != 0) ? 2 : 1;
       DkProfScope prof;
       dk_prof_begin(prof, st);
-      if (seg == 20)
-        wgrad3_launch<20, 1>(a, nblk, st);
+      if (S3 == 2)
+      {
+        if (vw == 4) wgrad3_launch<20, 4, 2>(a, nblk, st);
+        else if (vw == 2) wgrad3_launch<20, 2, 2>(a, nblk, st);
+        else wgrad3_launch<20, 1, 2>(a, nblk, st);
+      }
+      else if (seg == 20)
+        wgrad3_launch<20, 1, 1>(a, nblk, st);
       else if (vw == 4)
-        wgrad3_launch<40, 4>(a, nblk, st);
+        wgrad3_launch<40, 4, 1>(a, nblk, st);
       else if (vw == 2)
-        wgrad3_launch<40, 2>(a, nblk, st);
+        wgrad3_launch<40, 2, 1>(a, nblk, st);
       else
-        wgrad3_launch<40, 1>(a, nblk, st);
+        wgrad3_launch<40, 1, 1>(a, nblk, st);
       CHECK_HIP(hipPeekAtLastError());
       if (prof.e0)
       {
         char nm[96];
-        snprintf(nm, sizeof(nm), "conv_wgrad3_f32<%d, %d>", seg, seg == 20 ? 1 : vw);
+        snprintf(nm, sizeof(nm), "conv_wgrad3_f32<%d, %d, %d>", seg, (seg == 20 && S3 == 1) ? 1 : vw, S3);
         dk_prof_end(prof, st, dk_prof_named_slot(nm), 2.0 * (double)M * K * (double)a.N / 1e9);
       }
       if (det)

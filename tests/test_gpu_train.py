@@ -201,7 +201,7 @@ def test_every_training_kernel_variant_vs_oracle(gpu, case):
                         ran = [k for k in _ran_kernels(gpu.lib()) if k.startswith("conv_wgrad")]
                         seg = 20 if w <= 20 else 40
                         vw = 1 if (seg == 20 or avec == 0) else 4 if w % 4 == 0 else 2 if w % 2 == 0 else 1
-                        assert ran == ["conv_wgrad3_f32<%d, %d>" % (seg, vw)], ran
+                        assert ran == ["conv_wgrad3_f32<%d, %d, 1>" % (seg, vw)], ran
                         seen.add((ran[0], det))
                         util.assert_close(ddw.numpy().reshape(wt.shape), ref_dw,
                                           "wgrad3 %s avec %d deterministic %d" % (case, avec, det), atol_rms=wg_atol)
@@ -1284,3 +1284,59 @@ def test_clip_clamps_weights_after_the_update(gpu, tmp_path):
             assert np.array_equal(w1[i], np.clip(w0[i], np.float32(-0.02), np.float32(0.02))), "layer %d" % i
         else:
             assert np.array_equal(w1[i], w0[i]), "unclipped layer %d changed" % i
+
+
+WGRAD3_STRIDE2_SHAPES = [
+    # batch, c, h, w, n: 3x3 / stride 2 / pad 1 on even maps (yolov4's down-sampling layers are 64->128 304^2 ... 512->1024 38^2)
+    (2, 32, 16, 24, 128),      # one segment of 12 pixels, 16-byte pieces
+    (1, 64, 38, 38, 128),      # 19 output columns, 8-byte pieces, two channel tiles
+    (2, 32, 12, 88, 256),      # 44 output columns: three segments, the last 4 wide; two filter tiles
+    (1, 32, 6, 50, 128),       # width = 2 mod 4, 25 output columns: 4-byte pieces (a delta row is odd)
+    (1, 32, 8, 44, 128),       # 22 output columns: 8-byte pieces
+]
+
+
+@pytest.mark.parametrize("case", WGRAD3_STRIDE2_SHAPES)
+def test_row_staged_weight_gradient_stride2_vs_oracle(gpu, case):
+    """conv_wgrad3_f32<20, VW, 2> (conv_wgrad.hip): the weight gradient of the 3x3 / stride-2 layers, against the oracle's
+    BackwardConvolutionalLayer (src/convolutional_layer.cpp:1345-1356: im2col_cpu_ext + gemm(0,1)) accumulating into a
+    non-zero dW, with 16 / 8 / 4-byte pieces, atomics and the ordered reduction, both pixel splits; the gather kernel on the
+    same layer as a cross-check; each launch is checked to have run the kernel it names."""
+    batch, c, h, w, n = case
+    L, G = O.lib(), bind(gpu.lib())
+    G.dk_train_force.argtypes = [C.c_int, C.c_int]
+    G.dk_set_deterministic.argtypes = [C.c_int]
+    G.dk_set_deterministic.restype = None
+    rng = np.random.default_rng(util.seed_of(case))
+    oh, ow = h // 2, w // 2
+    x = rng.uniform(-1, 1, (batch, c, h, w)).astype(np.float32)
+    wt = (rng.uniform(-1, 1, (n, c, 3, 3)) * 0.2).astype(np.float32)
+    delta = rng.uniform(-1, 1, (batch, n, oh, ow)).astype(np.float32)
+    dw0 = rng.uniform(-1, 1, wt.shape).astype(np.float32)
+    ref_dw, ref_prev = dw0.copy(), np.zeros_like(x)
+    ws = np.zeros(oh * ow * 9 * c + 1, np.float32)
+    L.orc_conv_backward(O.fptr(x), O.fptr(wt), O.fptr(delta), O.fptr(ref_dw), O.fptr(ref_prev), O.fptr(ws),
+                        batch, c, h, w, n, 1, 3, 2, 2, 1, 1)
+    d = gpu.DkConvDesc(batch, c, h, w, n, 1, 3, 2, 2, 1, 1, O.LINEAR)
+    dx, dd = gpu.DeviceArray(x), gpu.DeviceArray(delta)
+    G.dk_profile_enable(1)
+    try:
+        for tile, avec, det in [(4, -1, 0), (4, -1, 1), (5, -1, 0), (4, 0, 0), (-1, -1, 0), (0, -1, 0)]:
+            G.dk_train_force(0, tile)
+            G.dk_train_force(2, avec)
+            G.dk_set_deterministic(det)
+            ddw = gpu.DeviceArray(dw0)
+            assert G.dk_conv_backward_weights(C.byref(d), dx.ptr, dd.ptr, ddw.ptr, None) == 0
+            ran = [k for k in _ran_kernels(gpu.lib()) if k.startswith("conv_wgrad")]
+            if tile == 0:
+                assert len(ran) == 1 and ran[0].startswith("conv_wgrad_f32<"), ran
+            else:
+                vw = 1 if avec == 0 else 4 if (w % 4 == 0 and ow % 4 == 0) else 2 if ow % 2 == 0 else 1
+                assert ran == ["conv_wgrad3_f32<20, %d, 2>" % vw], ran
+            util.assert_close(ddw.numpy().reshape(wt.shape), ref_dw, "wgrad3 stride 2 %s tile %d avec %d det %d" % (case, tile, avec, det))
+            ddw.free()
+    finally:
+        for k in range(3):
+            G.dk_train_force(k, -1)
+        G.dk_set_deterministic(-1)
+        G.dk_profile_enable(0)
