@@ -712,6 +712,9 @@ static bool wgrad_knob_tmaj()
 // filters a multiple of 128
 bool dk_wgrad3_applicable(const DkConvDesc* d)
 {
+  static const bool off = getenv("DK_WGRAD3") && !atoi(getenv("DK_WGRAD3"));   // DK_WGRAD3=0: A/B runs against the gather kernel
+  if (off)
+    return false;
   const bool s1 = d && d->stride_x == 1 && d->stride_y == 1;
   const bool s2 = d && d->stride_x == 2 && d->stride_y == 2 && d->h % 2 == 0 && d->w % 2 == 0;
   return d && d->size == 3 && (s1 || s2) && d->pad == 1 && d->dilation == 1 && d->groups == 1 &&
