@@ -571,7 +571,7 @@ void ForwardNetworkGpu(Network* net, NetworkState state)
     // yolo heads -> pinned host memory on the copy stream AS SOON AS the head exists (the reference pulls them
     // asynchronously inside ForwardYoloLayerGpu, yolo_layer.cpp:854-858): yolov4's 76x76 head is 94 of the 123 MB a batch
     // of 16 sends back and is final a fifth of the forward before its end, so most of the PCIe time runs under the
-    // remaining layers.  Inside a stream capture the event pair makes the copies a parallel branch of the graph.
+    // remaining layers.  (Never inside a stream capture: NetworkPredictDevice sets the flag only for plain launches.)
     if (net->pull_in_forward && !state.train && (l->type == YOLO || l->type == GAUSSIAN_YOLO) && pulled < 8)
     {
       hipStream_t cs = get_cuda_memcpy_stream();
@@ -630,7 +630,7 @@ void NetworkPredictDevice(Network* net, float* input_gpu)
 
   // (the head copies of the previous call were joined into the compute stream by that call's forward)
   net->copy_pending = 0;
-  net->pull_in_forward = net_pull_heads(net) ? 1 : 0;
+  const bool pull = net_pull_heads(net);
   int yolo_heads = 0;
   size_t head_bytes = 0;
   for (int i = 0; i < net->n; ++i)
@@ -639,20 +639,19 @@ void NetworkPredictDevice(Network* net, float* input_gpu)
       ++yolo_heads;
       head_bytes += (size_t)net->layers[i].batch * net->layers[i].outputs * sizeof(float);
     }
-  const bool late_pull = net->pull_in_forward && yolo_heads > 8;   // more heads than events: the old form, after the forward
-  if (late_pull)
-    net->pull_in_forward = 0;
 
-  // Large heads go out under PLAIN launches: a graph replay runs its copy branch after the kernels (measured, yolov4
-  // 608 b16, frames in / heads out: 809 images/s replayed, 919 launched, 930 without the heads), and at the batch sizes
-  // where the heads are tens of MB the launches hide behind the kernels anyway.
+  // Large heads go out under PLAIN launches, each as soon as its layer has run (ForwardNetworkGpu): captured into a graph
+  // the copy branch runs after the kernels (measured, yolov4 608 b16, frames in / heads out: 809 images/s replayed, 919
+  // launched, 930 without the heads), and at the batch sizes where the heads are tens of MB the launches hide behind the
+  // kernels anyway.  Small heads (batch 1-2) keep the replay and are copied after it -- the capture never touches the
+  // process-wide copy stream, so other host threads may use that stream meanwhile.
+  const bool big_heads = pull && head_bytes > ((size_t)8 << 20);
   const bool can_graph = net_graph(net) && !net->benchmark_layers && !net->wait_stream &&
-                         !dk_profile_is_on() && state.input == net->input_state_gpu &&
-                         !(net->pull_in_forward && head_bytes > ((size_t)8 << 20));
+                         !dk_profile_is_on() && state.input == net->input_state_gpu && !big_heads;
+  net->pull_in_forward = (pull && !can_graph && yolo_heads <= 8) ? 1 : 0;
+  const bool late_pull = pull && !net->pull_in_forward;
   if (can_graph)
   {
-    if (net->graph_exec && net->graph_pull != net->pull_in_forward)
-      DkInvalidateGraph(net);   // captured with / without the head copies
     if (!net->graph_exec)
     {
       hipGraph_t graph = nullptr;
@@ -663,7 +662,6 @@ void NetworkPredictDevice(Network* net, float* input_gpu)
       CHECK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
       CHECK_HIP(hipGraphDestroy(graph));
       net->graph_exec = exec;
-      net->graph_pull = net->pull_in_forward;
     }
     CHECK_HIP(hipGraphLaunch((hipGraphExec_t)net->graph_exec, st));
   }

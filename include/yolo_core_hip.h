@@ -345,7 +345,6 @@ struct Network
   void* copy_done_ev;    /* NetworkPredictDevice: head copies of the previous call finished */
   int copy_pending;
   int pull_in_forward;   /* NetworkPredictDevice -> ForwardNetworkGpu: copy every yolo head to the host as soon as its layer has run */
-  int graph_pull;        /* the captured forward contains those copies */
   void* head_ev[8];      /* one event per pulled head (hipEvent_t) */
   int opt_graph, opt_pull_heads; /* per-network overrides of DkSetGraph / DkSetPullHeads (0/1), -1... stored +1: 0 = follow the process-wide setting */
   void* sgd_plan;        /* multi-tensor SGD plan (one launch per update), or NULL */
