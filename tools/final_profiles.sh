@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round-end artifacts in one GPU call: the five profile directories of profiles/roundN_* from the CURRENT sources.
 # usage (through gpurun): bash tools/final_profiles.sh <name> [c3 c2 c5 c5x c4]   -> gpurun_out/<name>/<tag>/
+# (c4: run tools/bench_train.py once before, in the same call -- the first training run on a fresh box is ~4 % slower)
 R=${GRAFT_REPO_ROOT:-$PWD}
 NAME=$1; shift
 TAGS=${@:-c3 c2 c5 c5x c4}
