@@ -16,6 +16,8 @@
 // read with float4 loads when the image size allows; col taps use the forward
 // kernel's branch-free gather (per-stage padding mask of the thread's pixel,
 // out-of-range flag ORed into the byte offset, hardware bounds check).
+// 3x3 / pad 1 layers of stride 1 or 2 with channels % 32 == 0 and filters % 128 == 0 take conv_wgrad3_f32 further down
+// (row-staged operands, all nine taps per workgroup) unless a gather tile is forced or wins the first step's timing.
 #include <hip/hip_runtime.h>
 
 #include <map>
