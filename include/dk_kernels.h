@@ -219,8 +219,9 @@ DK_API int dk_bn_act_backward(float* delta, const float* x, const float* mean, c
 DK_API int dk_conv_backward_weights(const DkConvDesc* d, const float* x, const float* delta,
     float* weight_updates, void* stream);
 /* Test / diagnostics hook: force a variant of the weight-gradient kernel in this process.  knob 0: tile shape 0..3
- * (128x128, 64x128, 128x64, 64x64 rows x taps), knob 1: tap-major tiles (0 never, 1 where applicable), knob 2: 16-byte
- * delta loads (0 never); value < 0 restores the default.  Returns the previous value (-1 = default), -3 for an unknown
+ * (128x128, 64x128, 128x64, 64x64 rows x taps) of the gather kernel, 4 / 5 the row-staged kernel of the 3x3 layers with
+ * ~2 / ~1 workgroups per CU (where it applies; it is also the default there), knob 1: tap-major tiles (0 never, 1 where
+ * applicable), knob 2: 16 / 8-byte loads (0 never); value < 0 restores the default.  Returns the previous value (-1 = default), -3 for an unknown
  * knob.  Together with dk_conv_force_config (forward / data-gradient kernels) and dk_set_deterministic this reaches every
  * kernel the training step's first-step timing can choose. */
 DK_API int dk_train_force(int knob, int value);
